@@ -1,0 +1,86 @@
+"""CPU tests that pin the oracle (no GPU).
+
+* oracle/_ref (the reference's own scanner / Huffman / BMP code + dpu_stages.c)
+  against the SURVEY section 0.4 known-answer hash;
+* oracle/liboracle.so (plain-C port) against oracle/_ref, field by field;
+* both against the committed manifest (generated from oracle/_ref).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_bytes
+
+SURVEY_SHA256 = "11ab0c81cfc918410245c5ff0923f787219521073c094cbfd7e763f4b3444c1f"
+SURVEY_MD5 = "fa708c3f78f341909052666db44586d2"
+SURVEY_HEAD = "424d5e950800000000001a0000000c000000f4017701010018009ba59e99a39c"
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAMES = sorted(json.load(open(os.path.join(HERE, "golden", "manifest.json"))).keys())
+
+
+def test_known_answer_port(port):
+    out = port.decode(golden_bytes("ilsvrc_val_00000001"))
+    bmp = out["bmp"]
+    assert len(bmp) == 562526
+    assert bmp[:32].hex() == SURVEY_HEAD
+    assert hashlib.md5(bmp).hexdigest() == SURVEY_MD5
+    assert hashlib.sha256(bmp).hexdigest() == SURVEY_SHA256
+
+
+def test_known_answer_ref(ref, tmp_path):
+    jp = tmp_path / "a.jpg"
+    jp.write_bytes(golden_bytes("ilsvrc_val_00000001"))
+    rc, _ = ref.run_cli(str(jp), str(tmp_path / "a.bmp"))
+    assert rc == 0
+    assert hashlib.sha256((tmp_path / "a.bmp").read_bytes()).hexdigest() == SURVEY_SHA256
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_port_matches_manifest(port, manifest, name):
+    ent = manifest[name]
+    out = port.decode(golden_bytes(name), name="{path}")
+    if ent["rc"] != 0:
+        assert not out["valid"]
+        assert out["log"] == ent["stdout"]
+        return
+    assert out["valid"]
+    assert out["log"] == ent["stdout"]
+    assert (out["huff_rc"] == 0) == bool(ent["huff_ok"])
+    assert hashlib.sha256(out["coef"].tobytes()).hexdigest() == ent["coef_sha256"]
+    assert len(out["bmp"]) == ent["bmp_len"]
+    assert hashlib.sha256(out["bmp"]).hexdigest() == ent["bmp_sha256"]
+    i = out["info"]
+    assert [i["width"], i["height"], i["ncomp"], i["hsamp"], i["vsamp"], i["restart_interval"]] == ent["dims"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_port_matches_ref_fields(port, ref, tmp_path, name):
+    data = golden_bytes(name)
+    jp = tmp_path / (name + ".jpg")
+    jp.write_bytes(data)
+    r = ref.parse_and_huffman(str(jp))
+    p = port.parse(data)
+    assert r is not None
+    assert r["info"]["valid"] == p["info"]["valid"]
+    if not r["info"]["valid"]:
+        return
+    for k, v in r["info"].items():
+        assert p["info"][k] == v, k
+    assert np.array_equal(r["ecs"], p["ecs"])
+    assert np.array_equal(r["metadata"], p["metadata"])
+
+
+def test_stage_entry_points_compose(port):
+    """dequant -> idct -> colour one by one == orc_dpu_exec."""
+    out = port.decode(golden_bytes("env_61x45_420_q85_opt") if "env_61x45_420_q85_opt" in NAMES else golden_bytes(NAMES[0]))
+    meta = out["metadata"]
+    a = out["coef"][0].copy()
+    b = out["coef"][0].copy()
+    port.dpu_exec(meta, a)
+    for s in range(3):
+        port.dpu_stage(meta, b, s)
+    assert np.array_equal(a, b)
