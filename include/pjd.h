@@ -1,0 +1,183 @@
+/*
+ * pjd.h -- C ABI of the MI355X-native JPEG decode path (libpjd.so).
+ *
+ * This is the drop-in boundary for the UPMEM-DPU dispatch of
+ * jeun-990806/pim-jpeg-decoder.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ *   reference                                         this library
+ *   ------------------------------------------------  -------------------------------
+ *   DpuSet::allocate + load   decoder_host.cpp:32,268   pjd_open / pjd_close
+ *   decode_Huffman_data       jpeg_scanner.cpp:707      \
+ *   copy("metadata_buffer")   decoder_host.cpp:276       |  pjd_batch_create + _upload
+ *   copy("mcus")              decoder_host.cpp:277      /
+ *   exec()                    decoder_host.cpp:292      pjd_batch_decode (+ _sync)
+ *   copy(batch.mcus,"mcus")   decoder_host.cpp:308      pjd_batch_download
+ *   4 x dpus()[0]->copy(ctr)  decoder_host.cpp:309-312  pjd_batch_decode_timed
+ *   the per-DPU payload T0    decoder_dpu.c:57-58       pjd_exec_dpu_payload (literal)
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Thread model: one
+ * submitting thread per pjd_ctx (the reference has one consumer thread,
+ * decoder_host.cpp:213).  All functions return 0 on success or a negative
+ * PJD_E_* code; nothing here falls back to a CPU implementation -- without a
+ * usable gfx950 device pjd_open fails.
+ */
+#ifndef PJD_H
+#define PJD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PJD_VERSION 1
+
+/* ---- error codes (library level) ---------------------------------------- */
+#define PJD_OK              0
+#define PJD_E_NODEVICE     -1   /* no HIP device / not gfx950                   */
+#define PJD_E_HIP          -2   /* a HIP call failed (see pjd_last_error)       */
+#define PJD_E_ARG          -3   /* bad argument / descriptor outside envelope   */
+#define PJD_E_NOMEM        -4
+#define PJD_E_STATE        -5   /* call order violated (e.g. decode before upload) */
+
+/* ---- per-image status: the reference's Huffman error classes ------------- *
+ * (jpeg_scanner.cpp:470-514).  As in the reference (decoder_host.cpp:181 drops
+ * the bool), an image with a non-zero status still has its partial picture
+ * written: everything decoded before the error, grey (128) after it.          */
+#define PJD_ST_OK        0
+#define PJD_ST_DC_SYM    1   /* "Error - Invalid DC value (255)"                        */
+#define PJD_ST_DC_LEN    2   /* "Error - DC coefficient length greater than 11"         */
+#define PJD_ST_DC_BITS   3   /* "Error - Invalid DC value"                              */
+#define PJD_ST_AC_SYM    4   /* "Error - Invalid AC value"  (symbol)                    */
+#define PJD_ST_AC_RUN    5   /* "Error - Zero run-length exceeded block component"      */
+#define PJD_ST_AC_LEN    6   /* "Error - AC coefficient length greater than 10"         */
+#define PJD_ST_AC_BITS   7   /* "Error - Invalid AC value"  (value bits)                */
+
+/* ---- output formats ------------------------------------------------------- */
+#define PJD_OUT_RGB8   0   /* top-down, tightly packed R,G,B bytes: 3*W*H bytes              */
+#define PJD_OUT_BMP    1   /* the complete file image bmp_writer.cpp:19-67 would emit:
+                              26-byte BITMAPCOREHEADER file header, bottom-up B,G,R rows,
+                              (W % 4) zero bytes after each row                               */
+
+/* ---- descriptor flags ----------------------------------------------------- */
+#define PJD_F_STANDARD_RESTART  1u  /* restart at every `restart_interval`-th MCU (ITU T.81).
+                                       Default (flag clear) reproduces the reference's rule
+                                       (jpeg_scanner.cpp:723), which differs -- and garbles --
+                                       when luma sampling is not 1x1.                         */
+#define PJD_F_FORCE_SEQUENTIAL  2u  /* decode with the one-lane exact kernel (debug/diagnosis) */
+
+/* Huffman table as the reference's scanner holds it (jpeg.h:129-134):
+ * offsets[k] = number of codes of length <= k (offsets[0] = 0).               */
+typedef struct pjd_huff_table {
+    uint8_t offsets[17];
+    uint8_t symbols[162];
+    uint8_t set;
+} pjd_huff_table;
+
+/* One parsed baseline JPEG -- exactly the fields of the reference `Header`
+ * (jpeg.h:146-179) that its hot path consumes, plus the restart-segment
+ * offsets the reference's scanner throws away.                                */
+typedef struct pjd_image_desc {
+    uint32_t width, height;            /* pixels                                              */
+    uint8_t  num_components;           /* 1..3                                                */
+    uint8_t  h_samp, v_samp;           /* luma sampling factors, each 1 or 2                  */
+    uint8_t  comp_h[3], comp_v[3];     /* per component (chroma must be 1x1)                  */
+    uint8_t  comp_qt[3], comp_dc[3], comp_ac[3];   /* table selectors, each 0..3              */
+    uint8_t  qt_set[4];
+    uint32_t qt[4][64];                /* NATURAL order as filled through the reference's
+                                          zigzag_map (common.h:9-18, entry 48 = 38)           */
+    pjd_huff_table dc[4], ac[4];
+    uint32_t restart_interval;         /* DRI value, 0 = none                                 */
+    const uint8_t *ecs;                /* entropy-coded bytes, destuffed (FF00 -> FF) and with
+                                          RSTn removed == Header::huffman_data (jpeg.h:168)   */
+    uint64_t ecs_len;
+    const uint64_t *seg_offsets;       /* byte offset in `ecs` of each restart segment,
+                                          seg_offsets[0] == 0; NULL => one segment            */
+    uint32_t n_segments;
+    uint32_t flags;                    /* PJD_F_*                                             */
+    /* Sharding of ONE image over several devices (restart segments are
+     * independent): decode only segments [shard_first_seg, +shard_n_segs);
+     * shard_n_segs == 0 means "all".  The output buffer is always full-size;
+     * only the MCUs of the selected segments are written.                      */
+    uint32_t shard_first_seg, shard_n_segs;
+} pjd_image_desc;
+
+typedef struct pjd_ctx pjd_ctx;
+typedef struct pjd_batch pjd_batch;
+
+/* Kernel-level timing of one decode, HIP events on the context's stream.     */
+#define PJD_MAX_KERNELS 16
+typedef struct pjd_timings {
+    int32_t n;
+    float   ms[PJD_MAX_KERNELS];
+    char    name[PJD_MAX_KERNELS][32];
+    float   total_ms;                  /* first-start .. last-stop                            */
+} pjd_timings;
+
+typedef struct pjd_batch_info {
+    int32_t  n_images;
+    uint64_t pixels;                   /* sum of width*height                                 */
+    uint64_t ecs_bytes;                /* sum of ecs_len                                      */
+    uint64_t out_bytes;                /* sum of output sizes                                 */
+    uint64_t coef_bytes;               /* int16 coefficient scratch in HBM                    */
+    uint64_t n_data_units;
+    uint64_t n_subsequences;           /* Huffman decode lanes                                */
+    uint64_t device_bytes;             /* everything this batch holds in HBM                  */
+    int32_t  n_sequential;             /* images routed to the exact one-lane kernel up front */
+    int32_t  n_fallback;               /* images re-decoded by it after the last decode       */
+} pjd_batch_info;
+
+/* ---- context --------------------------------------------------------------- */
+int  pjd_version(void);
+int  pjd_open(int device_ordinal, pjd_ctx **out);
+void pjd_close(pjd_ctx *ctx);
+const char *pjd_last_error(pjd_ctx *ctx);   /* text of the last failure on this context       */
+const char *pjd_status_string(int status);  /* the reference's message for a PJD_ST_* value   */
+void *pjd_stream(pjd_ctx *ctx);             /* the hipStream_t all work is issued on          */
+
+/* ---- batch life cycle ------------------------------------------------------- *
+ * create : plan + allocate (host pinned staging and HBM); copies the descriptors,
+ *          the caller's ecs buffers may be released after pjd_batch_upload returns.
+ * upload : H2D of bitstreams, tables and work lists (asynchronous on the stream).
+ * decode : enqueue the kernels; inputs and outputs stay resident in HBM.
+ * download: D2H of pictures and statuses into caller memory, synchronises.
+ * A batch can be decoded any number of times after one upload.                 */
+int  pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images,
+                      int out_format, pjd_batch **out);
+int  pjd_batch_upload(pjd_batch *b);
+int  pjd_batch_decode(pjd_batch *b);
+int  pjd_batch_decode_timed(pjd_batch *b, pjd_timings *t);   /* same work, events per kernel  */
+int  pjd_batch_capture(pjd_batch *b);       /* record the decode as a hipGraph; later
+                                               pjd_batch_decode calls replay it               */
+int  pjd_batch_sync(pjd_batch *b);
+int  pjd_batch_download(pjd_batch *b, uint8_t *const *out, int32_t *status);
+int  pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info);
+uint64_t pjd_batch_output_size(pjd_batch *b, int image);
+void *pjd_batch_device_output(pjd_batch *b, int image);      /* device pointer (HBM)          */
+void *pjd_batch_device_status(pjd_batch *b);                 /* int32[n_images] in HBM        */
+void pjd_batch_destroy(pjd_batch *b);
+
+/* One call: create + upload + decode + download + destroy.                    */
+int  pjd_decode_batch(pjd_ctx *ctx, const pjd_image_desc *images, int n_images,
+                      int out_format, uint8_t *const *out, int32_t *status);
+
+/* ---- the literal DPU contract ---------------------------------------------- *
+ * metadata: n_dpus x u32[276]   (decoder_host.cpp:156-178 index map)
+ * mcus    : n_dpus x i16[19200] coefficients in, R/G/B samples out, both in the
+ *           reference's blk16 layout (decoder_dpu.c:134-156,361-390).
+ * Replaces copy/copy/exec/copy of decoder_host.cpp:276-308 one for one.        */
+int  pjd_exec_dpu_payload(pjd_ctx *ctx, const uint32_t *metadata, int16_t *mcus, int n_dpus);
+
+/* Host-only planning: what a batch of these images would occupy (no device needed).
+ * Fills everything in `info` except device_bytes / n_fallback.                   */
+int  pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pjd_batch_info *info);
+
+/* Size in bytes of one picture in a given output format.                      */
+uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_format);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PJD_H */

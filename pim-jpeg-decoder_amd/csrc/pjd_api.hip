@@ -1,0 +1,522 @@
+// pjd_api.hip -- the C ABI of include/pjd.h on top of the gfx950 kernels.
+//
+// Host-side flow of one batch (what replaces the reference's consumer thread,
+// reference src/decoder_host.cpp:213-350):
+//   create   plan (pjd_plan.cpp) + allocate HBM and pinned staging
+//   upload   one packed H2D copy of the bitstreams + the small work lists
+//   decode   memset(coefficients) -> table build -> Huffman sync / fix / carry / write ->
+//            DC scan -> exact kernel for the images routed to it -> fused IDCT/colour
+//   sync     read the status words; any image the parallel decoder flagged is re-decoded by the
+//            exact kernel (on the GPU) and its picture regenerated
+//   download one D2H copy per picture
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pjd.h"
+#include "pjd_kernels.h"
+#include "pjd_plan.h"
+
+struct pjd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool force_sequential = false;
+};
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return PJD_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dev_upload(pjd_ctx *ctx, T *&dptr, const std::vector<T> &v, size_t min_elems = 1)
+{
+    size_t n = v.size() > min_elems ? v.size() : min_elems;
+    HIP_TRY(ctx, hipMalloc((void **)&dptr, n * sizeof(T)));
+    HIP_TRY(ctx, hipMemsetAsync(dptr, 0, n * sizeof(T), ctx->stream));
+    if (!v.empty()) HIP_TRY(ctx, hipMemcpyAsync(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PJD_OK;
+}
+
+template <class T>
+int dev_alloc(pjd_ctx *ctx, T *&dptr, size_t n, uint64_t &total)
+{
+    if (n == 0) n = 1;
+    HIP_TRY(ctx, hipMalloc((void **)&dptr, n * sizeof(T)));
+    total += n * sizeof(T);
+    return PJD_OK;
+}
+
+}  // namespace
+
+struct pjd_batch {
+    pjd_ctx *ctx = nullptr;
+    PjdPlan plan;
+    PjdDevBatch dev{};
+    // owned device allocations (non-const views of what `dev` points to)
+    PjdDevImage *d_images = nullptr;
+    PjdDevHuffRaw *d_raw = nullptr;
+    uint16_t *d_qtab = nullptr;
+    PjdDevSegment *d_segs = nullptr;
+    PjdDevSub *d_subs = nullptr;
+    PjdDevHuffWg *d_hwgs = nullptr;
+    PjdDevIdctWg *d_iwgs = nullptr;
+    uint8_t *d_ecs = nullptr;
+    uint32_t *d_dcblk_image = nullptr;
+    uint32_t *d_seq_list = nullptr;      // images routed to the exact kernel up front
+    uint32_t *d_fb_list = nullptr;       // scratch list for fallback images
+    PjdDevIdctWg *d_fb_iwgs = nullptr;   // scratch IDCT work list for fallback images
+    int32_t *d_status_init = nullptr;
+    uint8_t *h_ecs = nullptr;            // pinned staging
+    int32_t *h_status = nullptr;         // pinned
+    std::vector<uint32_t> iwg_base, iwg_count;   // per image, into plan.iwgs
+    std::vector<uint32_t> seq_list;      // what d_seq_list holds
+    uint64_t device_bytes = 0;
+    bool uploaded = false, decoded = false, settled = false;
+    int n_fallback = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+};
+
+extern "C" {
+
+int pjd_version(void) { return PJD_VERSION; }
+
+int pjd_open(int device_ordinal, pjd_ctx **out)
+{
+    if (!out) return PJD_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return PJD_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return PJD_E_NODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PJD_E_NODEVICE;   // kernels are built for gfx950 only
+    pjd_ctx *c = new pjd_ctx;
+    c->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return PJD_E_HIP;
+    }
+    const char *fs = std::getenv("PJD_FORCE_SEQUENTIAL");
+    c->force_sequential = fs && fs[0] == '1';
+    *out = c;
+    return PJD_OK;
+}
+
+void pjd_close(pjd_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
+
+const char *pjd_last_error(pjd_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+const char *pjd_status_string(int status)
+{
+    switch (status & 0xFF) {   // reference src/jpeg_scanner.cpp:471,475,481,491,501,507,513
+        case PJD_ST_OK: return "";
+        case PJD_ST_DC_SYM: return "Error - Invalid DC value (255)";
+        case PJD_ST_DC_LEN: return "Error - DC coefficient length greater than 11";
+        case PJD_ST_DC_BITS: return "Error - Invalid DC value";
+        case PJD_ST_AC_SYM: return "Error - Invalid AC value";
+        case PJD_ST_AC_RUN: return "Error - Zero run-length exceeded block component";
+        case PJD_ST_AC_LEN: return "Error - AC coefficient length greater than 10";
+        case PJD_ST_AC_BITS: return "Error - Invalid AC value";
+        default: return "Error - unknown";
+    }
+}
+
+void *pjd_stream(pjd_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+void pjd_batch_destroy(pjd_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
+    if (b->graph) hipGraphDestroy(b->graph);
+    void *ptrs[] = { b->d_images, b->d_raw, b->d_qtab, b->d_segs, b->d_subs, b->d_hwgs, b->d_iwgs, b->d_ecs,
+                     b->d_dcblk_image, b->d_seq_list, b->d_fb_list, b->d_fb_iwgs, b->d_status_init,
+                     b->dev.luts, b->dev.coef, b->dev.out, b->dev.status, b->dev.sub_exit, b->dev.sub_cnt,
+                     b->dev.wg_entry, b->dev.wg_exit, b->dev.wg_agg, b->dev.wg_du_in, b->dev.dc_agg, b->dev.dc_carry };
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (b->h_ecs) hipHostFree(b->h_ecs);
+    if (b->h_status) hipHostFree(b->h_status);
+    delete b;
+}
+
+int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, int out_format, pjd_batch **out)
+{
+    if (!ctx || !out) return PJD_E_ARG;
+    *out = nullptr;
+    pjd_batch *b = new pjd_batch;
+    b->ctx = ctx;
+    int rc = pjd_make_plan(images, n_images, out_format, b->plan, ctx->err);
+    if (rc != PJD_OK) { delete b; return rc; }
+    PjdPlan &P = b->plan;
+    hipSetDevice(ctx->device);
+
+    // pinned staging for the packed bitstreams; filled now so the caller's buffers can go away
+    rc = PJD_OK;
+    auto fail = [&](int code) { pjd_batch_destroy(b); return code; };
+    if (hipHostMalloc((void **)&b->h_ecs, P.ecs_buf_bytes, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(ecs)"; return fail(PJD_E_NOMEM); }
+    std::memset(b->h_ecs, 0, P.ecs_buf_bytes);
+    for (int i = 0; i < n_images; i++)
+        if (P.host[i].ecs_copy_len) std::memcpy(b->h_ecs + P.images[i].ecs_off, P.host[i].ecs_src, P.host[i].ecs_copy_len);
+    if (hipHostMalloc((void **)&b->h_status, sizeof(int32_t) * (n_images + 1), hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(status)"; return fail(PJD_E_NOMEM); }
+
+    // per-image IDCT work-list ranges (for the fallback re-run)
+    b->iwg_base.assign(n_images, 0); b->iwg_count.assign(n_images, 0);
+    for (size_t k = 0; k < P.iwgs.size(); k++) {
+        uint32_t im = P.iwgs[k].image;
+        if (b->iwg_count[im] == 0) b->iwg_base[im] = (uint32_t)k;
+        b->iwg_count[im]++;
+    }
+
+    uint64_t &tot = b->device_bytes;
+#define TRY_RC(x) do { int rc_ = (x); if (rc_ != PJD_OK) return fail(rc_); } while (0)
+    TRY_RC(dev_alloc(ctx, b->d_images, P.images.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_raw, P.tables.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_qtab, P.qtab.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_segs, P.segs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_subs, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_hwgs, P.hwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_iwgs, P.iwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_fb_iwgs, P.iwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_ecs, P.ecs_buf_bytes, tot));
+    TRY_RC(dev_alloc(ctx, b->d_dcblk_image, P.n_dcblk, tot));
+    TRY_RC(dev_alloc(ctx, b->d_seq_list, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->d_fb_list, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->d_status_init, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.luts, P.tables.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.coef, P.n_du * 64, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.out, P.out_buf_bytes, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.sub_exit, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.sub_cnt, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.wg_entry, P.hwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.wg_exit, P.hwgs.size() * 2, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.wg_agg, P.hwgs.size() * 2, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.wg_du_in, P.hwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.dc_agg, P.n_dcblk * 4, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.dc_carry, P.n_dcblk * 4, tot));
+#undef TRY_RC
+    b->dev.images = b->d_images; b->dev.raw_tables = b->d_raw; b->dev.qtab = b->d_qtab;
+    b->dev.segs = b->d_segs; b->dev.subs = b->d_subs; b->dev.hwgs = b->d_hwgs; b->dev.iwgs = b->d_iwgs;
+    b->dev.ecs = b->d_ecs; b->dev.dcblk_image = b->d_dcblk_image;
+    b->dev.n_images = (uint32_t)n_images; b->dev.n_hwg = (uint32_t)P.hwgs.size();
+    b->dev.n_iwg = (uint32_t)P.iwgs.size(); b->dev.n_dcblk = (uint32_t)P.n_dcblk;
+    *out = b;
+    return PJD_OK;
+}
+
+int pjd_batch_upload(pjd_batch *b)
+{
+    if (!b) return PJD_E_ARG;
+    pjd_ctx *ctx = b->ctx;
+    PjdPlan &P = b->plan;
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+#define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(ctx, hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, s)); } while (0)
+    UP(b->d_images, P.images); UP(b->d_raw, P.tables); UP(b->d_qtab, P.qtab);
+    UP(b->d_segs, P.segs); UP(b->d_subs, P.subs); UP(b->d_hwgs, P.hwgs); UP(b->d_iwgs, P.iwgs);
+    std::vector<uint32_t> dcimg(P.n_dcblk);
+    for (size_t i = 0; i < P.images.size(); i++)
+        for (uint32_t k = 0; k < P.images[i].n_dcblk; k++) dcimg[P.images[i].dcblk_base + k] = (uint32_t)i;
+    UP(b->d_dcblk_image, dcimg);
+    // routing: images for the exact kernel, and the initial status words
+    b->seq_list = P.seq_images;
+    std::vector<int32_t> st0(P.images.size(), 0);
+    if (ctx->force_sequential) {
+        b->seq_list.clear();
+        for (size_t i = 0; i < P.images.size(); i++) b->seq_list.push_back((uint32_t)i);
+    }
+    for (uint32_t i : b->seq_list) st0[i] = PJD_STW_NEEDS_EXACT;
+    UP(b->d_seq_list, b->seq_list);
+    UP(b->d_status_init, st0);
+#undef UP
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_ecs, b->h_ecs, P.ecs_buf_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(b->dev.out, 0, P.out_buf_bytes, s));   // BMP row padding stays zero
+    HIP_TRY(ctx, hipStreamSynchronize(s));                              // the vectors above are pageable
+    b->uploaded = true;
+    return PJD_OK;
+}
+
+}  // extern "C"
+
+// ---- the decode sequence -------------------------------------------------------------------
+namespace {
+
+struct KernelTimer {
+    pjd_timings *t;
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;
+    std::vector<std::string> names;
+    void mark(const char *name)
+    {
+        if (!t) return;
+        hipEvent_t e;
+        hipEventCreate(&e);
+        hipEventRecord(e, s);
+        ev.push_back(e);
+        names.push_back(name);
+    }
+    void finish()
+    {
+        if (!t) return;
+        hipStreamSynchronize(s);
+        t->n = 0;
+        for (size_t k = 0; k + 1 < ev.size() && t->n < PJD_MAX_KERNELS; k++) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            t->ms[t->n] = ms;
+            std::snprintf(t->name[t->n], sizeof t->name[0], "%s", names[k + 1].c_str());
+            t->n++;
+        }
+        t->total_ms = 0;
+        if (ev.size() >= 2) hipEventElapsedTime(&t->total_ms, ev.front(), ev.back());
+        for (hipEvent_t e : ev) hipEventDestroy(e);
+    }
+};
+
+int enqueue_decode(pjd_batch *b, pjd_timings *timings)
+{
+    pjd_ctx *ctx = b->ctx;
+    PjdPlan &P = b->plan;
+    hipStream_t s = ctx->stream;
+    KernelTimer kt{timings, s, {}, {}};
+    const bool parallel = !ctx->force_sequential && !P.hwgs.empty();
+    kt.mark("start");
+    HIP_TRY(ctx, hipMemcpyAsync(b->dev.status, b->d_status_init, sizeof(int32_t) * P.images.size(), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, P.n_du * 64 * sizeof(int16_t), s));
+    kt.mark("memset_coef");
+    if (parallel) {
+        pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
+        pjd_launch_huff_sync(s, b->dev);     kt.mark("huff_sync");
+        pjd_launch_huff_fix(s, b->dev);      kt.mark("huff_fix");
+        pjd_launch_huff_carry(s, b->dev);    kt.mark("huff_carry");
+        pjd_launch_huff_write(s, b->dev);    kt.mark("huff_write");
+        pjd_launch_dc_scan(s, b->dev);       kt.mark("dc_scan");
+    }
+    if (!b->seq_list.empty()) {
+        pjd_launch_huff_sequential(s, b->dev, b->d_seq_list, (uint32_t)b->seq_list.size());
+        kt.mark("huff_sequential");
+    }
+    pjd_launch_idct_colour(s, b->dev, b->d_iwgs, (uint32_t)P.iwgs.size());
+    kt.mark("idct_colour");
+    HIP_TRY(ctx, hipGetLastError());
+    kt.finish();
+    b->decoded = true;
+    b->settled = false;
+    return PJD_OK;
+}
+
+// After the stream drained: re-decode, with the exact kernel, every image the parallel decoder
+// flagged.  Runs on the GPU; the coefficient range of such an image is cleared first.
+int settle(pjd_batch *b)
+{
+    pjd_ctx *ctx = b->ctx;
+    PjdPlan &P = b->plan;
+    hipStream_t s = ctx->stream;
+    if (b->settled || !b->decoded) return PJD_OK;
+    const size_t n = P.images.size();
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    std::vector<uint32_t> fb;
+    std::vector<char> was_seq(n, 0);
+    for (uint32_t i : b->seq_list) was_seq[i] = 1;
+    for (size_t i = 0; i < n; i++)
+        if ((b->h_status[i] & PJD_STW_NEEDS_EXACT) && !was_seq[i]) fb.push_back((uint32_t)i);
+    b->n_fallback = (int)fb.size();
+    if (!fb.empty()) {
+        std::vector<PjdDevIdctWg> wl;
+        for (uint32_t i : fb) {
+            if (P.images[i].first_mcu != 0 || P.images[i].last_mcu != P.images[i].n_mcu) {
+                ctx->err = "a sharded image needs the exact kernel (irregular restart segment)";
+                return PJD_E_ARG;
+            }
+            HIP_TRY(ctx, hipMemsetAsync(b->dev.coef + P.images[i].du_base * 64, 0, (size_t)P.images[i].n_du * 64 * sizeof(int16_t), s));
+            for (uint32_t k = 0; k < b->iwg_count[i]; k++) wl.push_back(P.iwgs[b->iwg_base[i] + k]);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_fb_list, fb.data(), fb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_fb_iwgs, wl.data(), wl.size() * sizeof(PjdDevIdctWg), hipMemcpyHostToDevice, s));
+        pjd_launch_huff_sequential(s, b->dev, b->d_fb_list, (uint32_t)fb.size());
+        pjd_launch_idct_colour(s, b->dev, b->d_fb_iwgs, (uint32_t)wl.size());
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    b->settled = true;
+    return PJD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pjd_batch_decode(pjd_batch *b)
+{
+    if (!b) return PJD_E_ARG;
+    if (!b->uploaded) { b->ctx->err = "decode before upload"; return PJD_E_STATE; }
+    hipSetDevice(b->ctx->device);
+    if (b->graph_exec) {
+        HIP_TRY(b->ctx, hipGraphLaunch(b->graph_exec, b->ctx->stream));
+        b->decoded = true; b->settled = false;
+        return PJD_OK;
+    }
+    return enqueue_decode(b, nullptr);
+}
+
+int pjd_batch_decode_timed(pjd_batch *b, pjd_timings *t)
+{
+    if (!b || !t) return PJD_E_ARG;
+    if (!b->uploaded) { b->ctx->err = "decode before upload"; return PJD_E_STATE; }
+    hipSetDevice(b->ctx->device);
+    std::memset(t, 0, sizeof *t);
+    return enqueue_decode(b, t);
+}
+
+int pjd_batch_capture(pjd_batch *b)
+{
+    if (!b) return PJD_E_ARG;
+    if (!b->uploaded) { b->ctx->err = "capture before upload"; return PJD_E_STATE; }
+    pjd_ctx *ctx = b->ctx;
+    hipSetDevice(ctx->device);
+    if (b->graph_exec) return PJD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_decode(b, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &b->graph);
+    b->decoded = false;
+    if (rc != PJD_OK) return rc;
+    if (e != hipSuccess) { ctx->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return PJD_E_HIP; }
+    HIP_TRY(ctx, hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0));
+    return PJD_OK;
+}
+
+int pjd_batch_sync(pjd_batch *b)
+{
+    if (!b) return PJD_E_ARG;
+    hipSetDevice(b->ctx->device);
+    if (b->decoded) return settle(b);
+    HIP_TRY(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    return PJD_OK;
+}
+
+int pjd_batch_download(pjd_batch *b, uint8_t *const *out, int32_t *status)
+{
+    if (!b) return PJD_E_ARG;
+    if (!b->decoded) { b->ctx->err = "download before decode"; return PJD_E_STATE; }
+    int rc = settle(b);
+    if (rc != PJD_OK) return rc;
+    pjd_ctx *ctx = b->ctx;
+    PjdPlan &P = b->plan;
+    if (out)
+        for (size_t i = 0; i < P.images.size(); i++)
+            if (out[i]) HIP_TRY(ctx, hipMemcpyAsync(out[i], b->dev.out + P.images[i].out_off, P.host[i].out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (status)
+        for (size_t i = 0; i < P.images.size(); i++) status[i] = b->h_status[i] & 0xFF;
+    return PJD_OK;
+}
+
+int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
+{
+    if (!b || !info) return PJD_E_ARG;
+    PjdPlan &P = b->plan;
+    std::memset(info, 0, sizeof *info);
+    info->n_images = (int32_t)P.images.size();
+    info->pixels = P.pixels; info->ecs_bytes = P.ecs_bytes; info->out_bytes = P.out_bytes;
+    info->coef_bytes = P.n_du * 64 * sizeof(int16_t);
+    info->n_data_units = P.n_du;
+    info->n_subsequences = P.subs.size();
+    info->device_bytes = b->device_bytes;
+    info->n_sequential = (int32_t)b->seq_list.size();
+    info->n_fallback = b->n_fallback;
+    return PJD_OK;
+}
+
+int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pjd_batch_info *info)
+{
+    if (!info) return PJD_E_ARG;
+    PjdPlan P;
+    std::string err;
+    int rc = pjd_make_plan(images, n_images, out_format, P, err);
+    if (rc != PJD_OK) return rc;
+    std::memset(info, 0, sizeof *info);
+    info->n_images = (int32_t)P.images.size();
+    info->pixels = P.pixels; info->ecs_bytes = P.ecs_bytes; info->out_bytes = P.out_bytes;
+    info->coef_bytes = P.n_du * 64 * sizeof(int16_t);
+    info->n_data_units = P.n_du;
+    info->n_subsequences = P.subs.size();
+    info->n_sequential = (int32_t)P.seq_images.size();
+    return PJD_OK;
+}
+
+uint64_t pjd_batch_output_size(pjd_batch *b, int image)
+{
+    if (!b || image < 0 || (size_t)image >= b->plan.host.size()) return 0;
+    return b->plan.host[image].out_bytes;
+}
+
+void *pjd_batch_device_output(pjd_batch *b, int image)
+{
+    if (!b || image < 0 || (size_t)image >= b->plan.host.size()) return nullptr;
+    return b->dev.out + b->plan.images[image].out_off;
+}
+
+void *pjd_batch_device_status(pjd_batch *b) { return b ? (void *)b->dev.status : nullptr; }
+
+int pjd_decode_batch(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, int out_format,
+                     uint8_t *const *out, int32_t *status)
+{
+    pjd_batch *b = nullptr;
+    int rc = pjd_batch_create(ctx, images, n_images, out_format, &b);
+    if (rc != PJD_OK) return rc;
+    rc = pjd_batch_upload(b);
+    if (rc == PJD_OK) rc = pjd_batch_decode(b);
+    if (rc == PJD_OK) rc = pjd_batch_download(b, out, status);
+    pjd_batch_destroy(b);
+    return rc;
+}
+
+int pjd_exec_dpu_payload(pjd_ctx *ctx, const uint32_t *metadata, int16_t *mcus, int n_dpus)
+{
+    if (!ctx || !metadata || !mcus || n_dpus < 0) return PJD_E_ARG;
+    if (n_dpus == 0) return PJD_OK;
+    for (int d = 0; d < n_dpus; d++) {
+        const uint32_t *m = metadata + (size_t)d * 276;
+        const uint32_t V = m[5] & 255, H = m[6] & 255;
+        if (m[19] != 100 || m[4] > 3 || (V != 1 && V != 2) || (H != 1 && H != 2)) { ctx->err = "DPU metadata outside the supported envelope"; return PJD_E_ARG; }
+        for (uint32_t c = 0; c < m[4]; c++) if ((m[7 + c] & 255) > 3) { ctx->err = "DPU metadata: quantisation table id > 3"; return PJD_E_ARG; }
+    }
+    hipSetDevice(ctx->device);
+    uint32_t *dm = nullptr; int16_t *dc = nullptr;
+    const size_t mb = (size_t)n_dpus * 276 * 4, cb = (size_t)n_dpus * 19200 * 2;
+    HIP_TRY(ctx, hipMalloc((void **)&dm, mb));
+    if (hipMalloc((void **)&dc, cb) != hipSuccess) { hipFree(dm); ctx->err = "hipMalloc(mcus)"; return PJD_E_NOMEM; }
+    int rc = PJD_OK;
+    auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == PJD_OK) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); rc = PJD_E_HIP; } };
+    chk(hipMemcpyAsync(dm, metadata, mb, hipMemcpyHostToDevice, ctx->stream), "copy(metadata_buffer)");
+    chk(hipMemcpyAsync(dc, mcus, cb, hipMemcpyHostToDevice, ctx->stream), "copy(mcus)");
+    if (rc == PJD_OK) { pjd_launch_dpu_payload(ctx->stream, dm, dc, n_dpus); chk(hipGetLastError(), "exec"); }
+    chk(hipMemcpyAsync(mcus, dc, cb, hipMemcpyDeviceToHost, ctx->stream), "copy back");
+    chk(hipStreamSynchronize(ctx->stream), "sync");
+    hipFree(dm); hipFree(dc);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// pjd_device_common.h -- arithmetic shared by every gfx950 kernel of the path.
+//
+// The integer contracts restated here are the reference's device code
+// (reference src/decoder_dpu.c); comments give the lines they follow.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pjd_internal.h"
+
+// zigzag slot -> natural position, with the reference's entry 48 = 38
+// (reference src/headers/common.h:9-18; the standard table has 58 there).
+static __constant__ uint8_t c_zz[64] = {
+     0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    38, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+};
+
+// One 1-D pass of the reference's integer butterfly (reference
+// src/decoder_dpu.c:219-267 rows, :271-319 columns).  32-bit ints, arithmetic
+// shifts, no rounding terms; the caller truncates the outputs to int16.
+__device__ __forceinline__ void pjd_idct8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7, int *o)
+{
+    const int g0 = (x0 * 181) >> 5, g1 = (x4 * 181) >> 5;
+    const int g2 = (x2 * 59) >> 3,  g3 = (x6 * 49) >> 4;
+    const int g4 = (x5 * 71) >> 4,  g5 = (x1 * 251) >> 5;
+    const int g6 = (x7 * 25) >> 4,  g7 = (x3 * 213) >> 5;
+    const int f4 = g4 - g7, f5 = g5 + g6, f6 = g5 - g6, f7 = g4 + g7;
+    const int e2 = g2 - g3, e3 = g2 + g3, e5 = f5 - f7, e7 = f5 + f7, e8 = f4 + f6;
+    const int d2 = (e2 * 181) >> 7, d4 = (f4 * 277) >> 8, d5 = (e5 * 181) >> 7;
+    const int d6 = (f6 * 669) >> 8, d8 = (e8 * 49) >> 6;
+    const int c0 = g0 + g1, c1 = g0 - g1, c2 = d2 - e3, c4 = d4 + d8;
+    const int c5 = d5 + e7, c6 = d6 - d8, c8 = c5 - c6;
+    const int b0 = c0 + e3, b1 = c1 + c2, b2 = c1 - c2, b3 = c0 - e3, b4 = c4 - c8, b6 = c6 - e7;
+    o[0] = (b0 + e7) >> 4; o[1] = (b1 + b6) >> 4; o[2] = (b2 + c8) >> 4; o[3] = (b3 + b4) >> 4;
+    o[4] = (b3 - b4) >> 4; o[5] = (b2 - c8) >> 4; o[6] = (b1 - b6) >> 4; o[7] = (b0 - e7) >> 4;
+}
+
+__device__ __forceinline__ int pjd_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// Fixed-point YCbCr -> RGB (reference src/decoder_dpu.c:376-382): 1.402, 0.344,
+// 0.714, 1.772 scaled by 2^22, every product shifted on its own, +128, clamp.
+__device__ __forceinline__ void pjd_ycc_to_rgb(int y, int cb, int cr, int &r, int &g, int &b)
+{
+    r = pjd_clamp255(y + ((int)(5880414u * (unsigned)cr) >> 22) + 128);
+    g = pjd_clamp255(y - ((int)(1442840u * (unsigned)cb) >> 22) - ((int)(2994733u * (unsigned)cr) >> 22) + 128);
+    b = pjd_clamp255(y + ((int)(7432306u * (unsigned)cb) >> 22) + 128);
+}
+
+// Dequantise: short *= u32 with the product truncated to int16 on store
+// (reference src/decoder_dpu.c:169-172); only the low 16 bits of q matter.
+__device__ __forceinline__ int pjd_dequant(int coef, unsigned q) { return (int)(int16_t)((unsigned)coef * q); }

@@ -1,0 +1,101 @@
+// pjd_internal.h -- data layout shared by the host planner and the gfx950 kernels.
+//
+// Everything the kernels read lives in HBM in these plain structs / arrays; the
+// host planner (pjd_plan.cpp) fills them from pjd_image_desc, the API
+// (pjd_api.hip) uploads them once per batch.
+#pragma once
+#include <stdint.h>
+
+// ---- tunables -----------------------------------------------------------------
+#define PJD_SUBSEQ_BYTES   128      // bitstream bytes per Huffman decode lane
+#define PJD_HUFF_THREADS   256      // lanes per Huffman workgroup
+#define PJD_HUFF_OWNED     255      // subsequences owned per workgroup (lane 0 = predecessor overlap)
+#define PJD_LUT_BITS       10       // first-level Huffman LUT width
+#define PJD_MAX_TABLES     6        // distinct Huffman tables one image can reference (3 DC + 3 AC)
+#define PJD_SYNC_MAX_ITERS 24       // intra-workgroup re-sync rounds before giving up (-> exact fallback)
+#define PJD_DC_BLOCK       256      // MCUs per DC-prediction scan block
+#define PJD_IDCT_THREADS   256
+#define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup
+#define PJD_COEF_SENTINEL  (-32768) // "slot 52 was visited with an explicit 0" (zigzag quirk)
+
+// ---- image flags (device side) -----------------------------------------------------
+#define PJD_IF_STANDARD_RESTART 1u  // restart every RI-th MCU; else the reference's (y*Wr+x)%RI rule
+#define PJD_IF_SEQUENTIAL       2u  // routed to the exact one-lane kernel up front
+#define PJD_IF_BMP              4u  // output is a BMP file image (else tight RGB8)
+
+// status word per image: low 8 bits = PJD_ST_* class, bit 8 = "fast path gave up, needs exact kernel"
+#define PJD_STW_NEEDS_EXACT 0x100
+
+struct PjdDevImage {
+    uint32_t width, height;
+    uint32_t mcux, mcuy, n_mcu;        // MCU grid (MCU = 8*hs x 8*vs pixels)
+    uint32_t ncomp, hs, vs;
+    uint32_t n_luma;                   // hs*vs
+    uint32_t dus_per_mcu;              // n_luma + ncomp - 1
+    uint32_t restart_interval;
+    uint32_t flags;
+    uint32_t ref_mcu_w, ref_mcu_h, ref_mcu_w_real;   // reference Header::mcu_width / mcu_height / mcu_width_real
+    uint32_t ecs_len;                  // bytes
+    uint64_t ecs_off;                  // into the batch bitstream buffer (16-byte aligned)
+    uint64_t du_base;                  // first data unit of this image in the coefficient buffer
+    uint32_t n_du;
+    uint32_t out_stride;               // bytes per output row (BMP: 3W + W%4, RGB8: 3W)
+    uint64_t out_off;                  // into the batch output buffer (256-byte aligned)
+    uint32_t seg_base, n_seg;          // into PjdDevSegment[]
+    uint32_t sub_base, n_sub;          // into PjdDevSub[]
+    uint32_t hwg_base, n_hwg;          // Huffman workgroups of this image
+    uint32_t dcblk_base, n_dcblk;      // DC scan blocks of this image
+    uint32_t first_mcu, last_mcu;      // MCU range this shard decodes: [first_mcu, last_mcu)
+    uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1
+    uint8_t  n_tables;
+    uint8_t  pad_[9];
+};
+
+// raw Huffman table as shipped by the host (reference HuffmanTable, jpeg.h:129-134)
+struct PjdDevHuffRaw {
+    uint8_t offsets[17];
+    uint8_t symbols[162];
+    uint8_t is_ac;
+};                                     // 180 bytes
+
+// decode-ready table, built on the device by pjd_k_build_tables
+struct PjdDevHuffLut {
+    uint16_t lut[1 << PJD_LUT_BITS];   // (code length << 8) | symbol ; 0 => longer than LUT_BITS or invalid
+    uint32_t first[17];                // first[L] = code value of the first code of length L (reference generate_codes)
+    uint8_t  offs[20];                 // offsets[0..16]
+    uint8_t  symbols[164];
+};                                     // 2048 + 68 + 20 + 164 = 2300 bytes
+#define PJD_LUT_STRUCT_BYTES 2300
+
+struct PjdDevSegment {                 // one restart segment
+    uint32_t byte_start;               // relative to the image's ecs
+    uint32_t byte_end;
+    uint32_t first_du;                 // image-relative index of its first data unit
+    uint32_t n_du;
+};
+
+struct PjdDevSub {                     // one Huffman subsequence (decode lane)
+    uint32_t byte_start;               // relative to the image's ecs
+    uint32_t seg;                      // global segment index | (1u<<31 if first subsequence of its segment)
+};
+
+struct PjdDevHuffWg {                  // one Huffman workgroup
+    uint32_t image;
+    uint32_t first_sub;                // global subsequence index of the first OWNED subsequence
+    uint32_t n_sub;                    // owned, 1..PJD_HUFF_OWNED
+    uint32_t pad_;
+};
+
+struct PjdDevIdctWg {                  // one IDCT/colour workgroup
+    uint32_t image;
+    uint32_t first_mcu;
+    uint32_t n_mcu;
+    uint32_t pad_;
+};
+
+// packed decoder state at a subsequence boundary: bit position (relative to the
+// image's ecs), data-unit phase within the MCU, zigzag slot
+static inline __host__ __device__ uint64_t pjd_pack_state(uint32_t p, uint32_t c, uint32_t z)
+{
+    return (uint64_t)p | ((uint64_t)c << 32) | ((uint64_t)z << 40);
+}

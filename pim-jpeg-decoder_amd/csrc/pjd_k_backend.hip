@@ -1,0 +1,331 @@
+// pjd_k_backend.hip -- gfx950 kernels behind the entropy decoder:
+//
+//   pjd_k_dpu_payload   the reference's per-DPU contract, one workgroup per 16x16 "block"
+//                       (reference src/decoder_dpu.c:82-390)
+//   pjd_k_dc_local /    DC prediction as a two-level segmented scan over MCUs
+//   pjd_k_dc_carry      (reference src/jpeg_scanner.cpp:485-486,723-727)
+//   pjd_k_idct_colour   fused de-zigzag + dequantise + 8x8 IDCT + chroma upsample +
+//                       YCbCr->RGB + raster store (reference src/decoder_dpu.c:158-390 and
+//                       src/bmp_writer.cpp:43-65 for the BMP row order)
+//
+// HBM-bound integer work: coefficients are read once with 16-byte loads, tiles
+// live in LDS (row stride 144 B so that the column pass is bank-conflict free),
+// pictures are written once.
+#include "pjd_device_common.h"
+#include "pjd_kernels.h"
+
+#define TILE_STRIDE 72   // int16 per data unit in LDS: 64 + 8 pad (144 B = 36 banks)
+
+// ---------------------------------------------------------------------------------------------
+// Literal DPU payload: metadata u32[276] + mcus i16[19200] per DPU.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void pjd_k_dpu_payload(const uint32_t *__restrict__ meta_all, int16_t *__restrict__ mcus_all)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[12][TILE_STRIDE];   // [comp*4 + pos][64]
+    const int dpu = blockIdx.x / 25, blk = blockIdx.x % 25;
+    const uint32_t *m = meta_all + (size_t)dpu * 276;
+    int16_t *base = mcus_all + (size_t)dpu * 19200 + blk * 768;
+    const int tid = threadIdx.x;
+    const int ncomp = (int)m[4];
+    const int V = (int)(m[5] & 255), H = (int)(m[6] & 255);
+
+    // dequantise (decoder_dpu.c:158-177) and row pass (:218-268): lane owns one row
+    if (tid < 96) {
+        const int du = tid >> 3, r = tid & 7, comp = du >> 2;
+        const int4 raw = *reinterpret_cast<const int4 *>(base + du * 64 + r * 8);
+        const int16_t *rv = reinterpret_cast<const int16_t *>(&raw);
+        int x[8], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = rv[j];
+        if (comp < ncomp) {
+            const uint32_t *q = m + 20 + (m[7 + comp] & 255) * 64 + r * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = pjd_dequant(x[j], q[j]);
+        }
+        pjd_idct8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tile[du][r * 8 + j] = (int16_t)o[j];
+    }
+    __syncthreads();
+    // column pass (decoder_dpu.c:270-320)
+    if (tid < 96) {
+        const int du = tid >> 3, c = tid & 7;
+        int x[8], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = tile[du][j * 8 + c];
+        pjd_idct8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tile[du][j * 8 + c] = (int16_t)o[j];
+    }
+    __syncthreads();
+    // colour (decoder_dpu.c:323-390).  (cbcr_index, v, h) per position follow the four tuples
+    // of each sampling mode; all reads come from LDS, all writes go to HBM, so the
+    // reference's in-place ordering constraints disappear.
+    for (int i = tid; i < 256; i += 128) {
+        const int pos = i >> 6, p = i & 63, y = p >> 3, x = p & 7;
+        int cidx, v, h;
+        if (V == 1 && H == 1)      { cidx = pos;     v = 0;        h = 0; }
+        else if (V == 2 && H == 1) { cidx = pos & 1; v = pos >> 1; h = 0; }
+        else if (V == 1 && H == 2) { cidx = pos & 2; v = 0;        h = pos & 1; }
+        else                       { cidx = 0;       v = pos >> 1; h = pos & 1; }
+        const int q = ((y / V) + 4 * v) * 8 + (x / H) + 4 * h;
+        int r, g, b;
+        pjd_ycc_to_rgb(tile[pos][p], tile[4 + cidx][q], tile[8 + cidx][q], r, g, b);
+        base[pos * 64 + p] = (int16_t)r;
+        base[256 + pos * 64 + p] = (int16_t)g;
+        base[512 + pos * 64 + p] = (int16_t)b;
+    }
+}
+
+void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus)
+{
+    hipLaunchKernelGGL(pjd_k_dpu_payload, dim3(n_dpus * 25), dim3(128), 0, s, metadata, mcus);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DC prediction.  After the parallel entropy decode, slot 0 of every data unit holds the DC
+// DIFFERENCE.  Level 1: each workgroup takes PJD_DC_BLOCK MCUs of one image, scans the
+// per-component sums with resets at restart points, and rewrites slot 0 with the prediction
+// relative to the block start.  Level 2: one wave per image scans the block aggregates.  The
+// IDCT kernel adds the carry.  All sums are modulo 2^16 like the reference's `short` stores.
+// ---------------------------------------------------------------------------------------------
+struct DcTriple { uint32_t y, cb, cr, f; };
+
+__global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_dc_local(PjdDevBatch B)
+{
+    __shared__ uint32_t sy[PJD_DC_BLOCK], scb[PJD_DC_BLOCK], scr[PJD_DC_BLOCK], sf[PJD_DC_BLOCK];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t ii = B.dcblk_image[b];
+    const PjdDevImage &im = B.images[ii];
+    uint32_t *agg = B.dc_agg + (size_t)b * 4;
+    const bool exact = (im.flags & PJD_IF_SEQUENTIAL) || (B.status[ii] & PJD_STW_NEEDS_EXACT);
+    if (exact) {                       // slot 0 already holds absolute DC values
+        if (tid < 4) agg[tid] = 0;
+        return;
+    }
+    const uint32_t m = (b - im.dcblk_base) * PJD_DC_BLOCK + tid;
+    const bool live = m >= im.first_mcu && m < im.last_mcu;
+    const uint32_t RI = im.restart_interval, dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp;
+    int16_t *du0 = B.coef + (im.du_base + (uint64_t)m * dus) * 64;
+    uint32_t d[6] = {0, 0, 0, 0, 0, 0};     // fully unrolled below: stays in registers
+    uint32_t vy = 0, vcb = 0, vcr = 0, head = 0;
+    if (live) {
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++)
+            if (k < dus) {
+                const uint32_t dv = (uint32_t)(int32_t)du0[k * 64];
+                d[k] = dv;
+                if (k < nl) vy += dv; else if (k == nl) vcb = dv; else vcr = dv;
+            }
+        head = (m == im.first_mcu) || (RI != 0 && m % RI == 0);
+    }
+    sy[tid] = vy; scb[tid] = vcb; scr[tid] = vcr; sf[tid] = head;
+    __syncthreads();
+    // Hillis-Steele inclusive segmented scan
+    for (uint32_t off = 1; off < PJD_DC_BLOCK; off <<= 1) {
+        uint32_t ay = 0, acb = 0, acr = 0, af = 0;
+        const bool take = tid >= off;
+        if (take) { ay = sy[tid - off]; acb = scb[tid - off]; acr = scr[tid - off]; af = sf[tid - off]; }
+        const uint32_t myf = sf[tid];
+        __syncthreads();
+        if (take) {
+            if (!myf) { sy[tid] += ay; scb[tid] += acb; scr[tid] += acr; }
+            sf[tid] = myf | af;
+        }
+        __syncthreads();
+    }
+    if (live) {
+        uint32_t py = 0, pcb = 0, pcr = 0;            // prediction entering this MCU
+        if (!head && tid > 0) { py = sy[tid] - vy; pcb = scb[tid] - vcb; pcr = scr[tid] - vcr; }
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++)
+            if (k < dus) {
+                uint32_t val;
+                if (k < nl) { py += d[k]; val = py; }
+                else if (k == nl) val = pcb + d[k];
+                else val = pcr + d[k];
+                du0[k * 64] = (int16_t)val;
+            }
+    }
+    if (tid == PJD_DC_BLOCK - 1) { agg[0] = sy[tid]; agg[1] = scb[tid]; agg[2] = scr[tid]; agg[3] = sf[tid]; }
+}
+
+__device__ __forceinline__ DcTriple dc_combine(const DcTriple &a, const DcTriple &b)   // a then b
+{
+    DcTriple r;
+    r.y = b.f ? b.y : a.y + b.y; r.cb = b.f ? b.cb : a.cb + b.cb; r.cr = b.f ? b.cr : a.cr + b.cr;
+    r.f = a.f | b.f;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void pjd_k_dc_carry(PjdDevBatch B)
+{
+    const PjdDevImage &im = B.images[blockIdx.x];
+    const uint32_t lane = threadIdx.x, n = im.n_dcblk;
+    DcTriple carry = {0, 0, 0, 0};
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t j = base + lane;
+        DcTriple v = {0, 0, 0, 0};
+        if (j < n) { const uint32_t *a = B.dc_agg + (size_t)(im.dcblk_base + j) * 4; v.y = a[0]; v.cb = a[1]; v.cr = a[2]; v.f = a[3]; }
+        for (int off = 1; off < 64; off <<= 1) {
+            DcTriple o;
+            o.y = __shfl_up(v.y, off); o.cb = __shfl_up(v.cb, off); o.cr = __shfl_up(v.cr, off); o.f = __shfl_up(v.f, off);
+            if ((int)lane >= off) v = dc_combine(o, v);
+        }
+        DcTriple prev;                     // inclusive result of lane-1
+        prev.y = __shfl_up(v.y, 1); prev.cb = __shfl_up(v.cb, 1); prev.cr = __shfl_up(v.cr, 1); prev.f = __shfl_up(v.f, 1);
+        DcTriple in = (lane == 0) ? carry : dc_combine(carry, prev);
+        if (j < n) { uint32_t *c = B.dc_carry + (size_t)(im.dcblk_base + j) * 4; c[0] = in.y; c[1] = in.cb; c[2] = in.cr; c[3] = 0; }
+        DcTriple last;
+        last.y = __shfl(v.y, 63); last.cb = __shfl(v.cb, 63); last.cr = __shfl(v.cr, 63); last.f = __shfl(v.f, 63);
+        carry = dc_combine(carry, last);
+        carry.f = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused back end.  One workgroup = up to 96 data units = a run of consecutive MCUs of one image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
+    __shared__ uint16_t qs[3][64];
+
+    const PjdDevIdctWg wg = wgs[blockIdx.x];
+    const PjdDevImage &im = B.images[wg.image];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp, hs = im.hs, vs = im.vs;
+    const uint32_t n_du = wg.n_mcu * dus;
+    const uint32_t RI = im.restart_interval;
+    const bool dc_abs = (im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT);
+
+    if (tid < 192) qs[tid >> 6][tid & 63] = B.qtab[(size_t)wg.image * 192 + tid];
+    __syncthreads();
+
+    // ---- load (16 B per lane, coalesced), DC fix-up, de-zigzag, dequantise, row pass ----------
+    // lane (du, r) owns zigzag slots 8r..8r+7 on load; after the scatter to natural order a
+    // second sweep does the row pass.
+    const int16_t *cbase = B.coef + (im.du_base + (uint64_t)wg.first_mcu * dus) * 64;
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
+        const uint32_t du = i >> 3, r = i & 7;
+        const uint32_t ml = du / dus, k = du - ml * dus;
+        const uint32_t comp = k < nl ? 0 : k - nl + 1;
+        const int4 raw = *reinterpret_cast<const int4 *>(cbase + (size_t)du * 64 + r * 8);
+        const int16_t *rv = reinterpret_cast<const int16_t *>(&raw);
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = rv[j];
+        if (r == 0 && !dc_abs) {
+            const uint32_t m = wg.first_mcu + ml;
+            const uint32_t blk = m / PJD_DC_BLOCK;
+            const uint32_t hm = RI ? (m / RI) * RI : 0;      // last restart point at or before m
+            if (hm < blk * PJD_DC_BLOCK) {                    // none inside this scan block: carry applies
+                const uint32_t *c = B.dc_carry + (size_t)(im.dcblk_base + blk) * 4;
+                v[0] = (int)(int16_t)((uint32_t)v[0] + c[comp]);
+            }
+        }
+        int16_t *t = tile[du];
+        const uint16_t *q = qs[comp];
+        if (r == 6) {
+            // slots 48..55.  Natural position 38 is the target of slot 48 AND slot 52 (the
+            // reference's zigzag_map[48] = 38): the later write wins, and an explicit zero
+            // written at slot 52 (run/size symbol with size 0) is marked by the sentinel.
+            const int v52 = v[4];
+            const int n38 = v52 != 0 ? (v52 == PJD_COEF_SENTINEL ? 0 : v52) : v[0];
+            t[38] = (int16_t)pjd_dequant(n38, q[38]);
+            t[59] = (int16_t)pjd_dequant(v[1], q[59]);
+            t[52] = (int16_t)pjd_dequant(v[2], q[52]);
+            t[45] = (int16_t)pjd_dequant(v[3], q[45]);
+            t[31] = (int16_t)pjd_dequant(v[5], q[31]);
+            t[39] = (int16_t)pjd_dequant(v[6], q[39]);
+            t[46] = (int16_t)pjd_dequant(v[7], q[46]);
+            t[58] = 0;                    // natural 58 is never written by the reference
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t nat = c_zz[r * 8 + j];
+                t[nat] = (int16_t)pjd_dequant(v[j], q[nat]);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {      // rows
+        const uint32_t du = i >> 3, r = i & 7;
+        int4 raw = *reinterpret_cast<const int4 *>(&tile[du][r * 8]);
+        int16_t *rv = reinterpret_cast<int16_t *>(&raw);
+        int o[8];
+        pjd_idct8(rv[0], rv[1], rv[2], rv[3], rv[4], rv[5], rv[6], rv[7], o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) rv[j] = (int16_t)o[j];
+        *reinterpret_cast<int4 *>(&tile[du][r * 8]) = raw;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {      // columns
+        const uint32_t du = i >> 3, c = i & 7;
+        int x[8], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = tile[du][j * 8 + c];
+        pjd_idct8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) tile[du][j * 8 + c] = (int16_t)o[j];
+    }
+    __syncthreads();
+
+    // ---- chroma upsample (nearest neighbour, decoder_dpu.c:370), colour, raster store --------
+    const uint32_t mw = 8 * hs, mh = 8 * vs;
+    const uint32_t n_px = wg.n_mcu * mw * mh;
+    const bool bmp = (im.flags & PJD_IF_BMP) != 0;
+    uint8_t *out = B.out + im.out_off;
+    if (bmp && wg.first_mcu == 0 && tid < 26) {
+        // file header exactly as reference src/bmp_writer.cpp:32-41
+        const uint32_t size = 26 + im.height * im.out_stride;
+        uint8_t hb = 0;
+        switch (tid) {
+            case 0: hb = 'B'; break;  case 1: hb = 'M'; break;
+            case 2: hb = size & 255; break; case 3: hb = (size >> 8) & 255; break;
+            case 4: hb = (size >> 16) & 255; break; case 5: hb = (size >> 24) & 255; break;
+            case 10: hb = 0x1A; break; case 14: hb = 12; break;
+            case 18: hb = im.width & 255; break; case 19: hb = (im.width >> 8) & 255; break;
+            case 20: hb = im.height & 255; break; case 21: hb = (im.height >> 8) & 255; break;
+            case 22: hb = 1; break; case 24: hb = 24; break;
+            default: hb = 0;
+        }
+        out[tid] = hb;
+    }
+    for (uint32_t i = tid; i < n_px; i += PJD_IDCT_THREADS) {
+        const uint32_t px = i % mw;
+        const uint32_t t = i / mw;
+        const uint32_t ml = t % wg.n_mcu, py = t / wg.n_mcu;
+        const uint32_t m = wg.first_mcu + ml;
+        const uint32_t my = m / im.mcux, mx = m - my * im.mcux;
+        const uint32_t X = mx * mw + px, Y = my * mh + py;
+        if (X >= im.width || Y >= im.height) continue;
+        const uint32_t d0 = ml * dus;
+        const int yv = tile[d0 + (py >> 3) * hs + (px >> 3)][(py & 7) * 8 + (px & 7)];
+        const uint32_t q = (py / vs) * 8 + (px / hs);
+        const int cb = nc > 1 ? tile[d0 + nl][q] : 0;
+        const int cr = nc > 2 ? tile[d0 + nl + 1][q] : 0;
+        int r, g, b;
+        pjd_ycc_to_rgb(yv, cb, cr, r, g, b);
+        if (bmp) {
+            uint8_t *o = out + 26 + (size_t)(im.height - 1 - Y) * im.out_stride + X * 3;
+            o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
+        } else {
+            uint8_t *o = out + (size_t)Y * im.out_stride + X * 3;
+            o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+        }
+    }
+}
+
+void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)
+{
+    if (n_wg == 0) return;
+    hipLaunchKernelGGL(pjd_k_idct_colour, dim3(n_wg), dim3(PJD_IDCT_THREADS), 0, s, b, wgs);
+}
+
+void pjd_launch_dc_scan(hipStream_t s, const PjdDevBatch &b)
+{
+    if (b.n_dcblk == 0) return;
+    hipLaunchKernelGGL(pjd_k_dc_local, dim3(b.n_dcblk), dim3(PJD_DC_BLOCK), 0, s, b);
+    hipLaunchKernelGGL(pjd_k_dc_carry, dim3(b.n_images), dim3(64), 0, s, b);
+}

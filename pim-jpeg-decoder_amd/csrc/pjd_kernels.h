@@ -1,0 +1,46 @@
+// pjd_kernels.h -- launchers of the gfx950 kernels (implemented in pjd_k_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pjd_internal.h"
+
+// All device pointers of one batch, as the kernels see them.
+struct PjdDevBatch {
+    const PjdDevImage *images;
+    const PjdDevHuffRaw *raw_tables;     // n_images * PJD_MAX_TABLES
+    PjdDevHuffLut *luts;                 // n_images * PJD_MAX_TABLES
+    const uint16_t *qtab;                // n_images * 3 * 64
+    const PjdDevSegment *segs;
+    const PjdDevSub *subs;
+    const PjdDevHuffWg *hwgs;
+    const PjdDevIdctWg *iwgs;
+    const uint8_t *ecs;
+    int16_t *coef;                       // n_du * 64, zigzag-slot order
+    uint8_t *out;
+    int32_t *status;                     // per image
+    // Huffman synchronisation scratch
+    uint64_t *sub_exit;                  // per subsequence: packed state at its end
+    uint32_t *sub_cnt;                   // per subsequence: data units completed inside it
+    uint64_t *wg_entry;                  // per Huffman workgroup: entry state it assumed for its first owned subsequence
+    uint64_t *wg_exit;                   // [2][n_hwg]: exit state of its last owned subsequence, generation 0/1
+    uint32_t *wg_agg;                    // per Huffman workgroup: {value, has_head}
+    uint32_t *wg_du_in;                  // per Huffman workgroup: absolute data-unit index at its entry
+    // DC prediction scratch
+    uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
+    uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
+    const uint32_t *dcblk_image;         // per DC block: owning image
+    uint32_t n_images, n_hwg, n_iwg, n_dcblk;
+};
+
+// ---- back end (pjd_k_backend.hip) ------------------------------------------------
+void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus);
+void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg);
+void pjd_launch_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernels: local scan + carry
+// ---- entropy decode (pjd_k_huffman.hip) -----------------------------------------
+void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, uint32_t n);
+void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
+void pjd_launch_huff_sync(hipStream_t s, const PjdDevBatch &b);
+void pjd_launch_huff_fix(hipStream_t s, const PjdDevBatch &b);
+void pjd_launch_huff_carry(hipStream_t s, const PjdDevBatch &b);
+void pjd_launch_huff_write(hipStream_t s, const PjdDevBatch &b);

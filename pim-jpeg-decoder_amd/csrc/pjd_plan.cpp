@@ -1,0 +1,224 @@
+// pjd_plan.cpp -- host-side batch planner (no HIP calls; runs anywhere).
+//
+// Turns the parsed-JPEG descriptors (the fields of the reference `Header`,
+// reference src/headers/jpeg.h:146-179) into the flat arrays the gfx950 kernels
+// walk: per-image geometry, restart segments, Huffman subsequences (one decode
+// lane each), Huffman workgroups, IDCT/colour workgroups, packed table sets.
+#include "pjd_plan.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+bool same_table(const pjd_huff_table &a, const pjd_huff_table &b)
+{
+    return std::memcmp(a.offsets, b.offsets, 17) == 0 && std::memcmp(a.symbols, b.symbols, 162) == 0;
+}
+
+std::string fmt(const char *f, int i, long a = 0, long b = 0)
+{
+    char buf[256];
+    std::snprintf(buf, sizeof buf, f, i, a, b);
+    return buf;
+}
+
+}  // namespace
+
+extern "C" uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_format)
+{
+    if (out_format == PJD_OUT_BMP)   // reference src/bmp_writer.cpp:28-29 (its own padding rule: W % 4)
+        return 26ull + (uint64_t)height * ((uint64_t)width * 3 + width % 4);
+    return (uint64_t)width * height * 3;
+}
+
+int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &P, std::string &err)
+{
+    if (n < 0 || (n > 0 && !images)) { err = "null image array"; return PJD_E_ARG; }
+    if (out_format != PJD_OUT_RGB8 && out_format != PJD_OUT_BMP) { err = "unknown output format"; return PJD_E_ARG; }
+    P = PjdPlan();
+    P.out_format = out_format;
+    P.images.resize(n);
+    P.host.resize(n);
+    P.tables.assign((size_t)n * PJD_MAX_TABLES, PjdDevHuffRaw());
+    P.qtab.assign((size_t)n * 3 * 64, 0);
+
+    uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0;
+    for (int i = 0; i < n; i++) {
+        const pjd_image_desc &d = images[i];
+        PjdDevImage &g = P.images[i];
+        PjdHostImage &h = P.host[i];
+        std::memset(&g, 0, sizeof g);
+
+        // ---- envelope: exactly what the reference scanner lets through (jpeg_scanner.cpp:187-285)
+        if (d.width == 0 || d.height == 0 || d.width > 65535 || d.height > 65535) { err = fmt("image %d: bad dimensions", i); return PJD_E_ARG; }
+        if (d.num_components < 1 || d.num_components > 3) { err = fmt("image %d: num_components must be 1..3", i); return PJD_E_ARG; }
+        if ((d.h_samp != 1 && d.h_samp != 2) || (d.v_samp != 1 && d.v_samp != 2)) { err = fmt("image %d: luma sampling must be 1 or 2", i); return PJD_E_ARG; }
+        if (d.comp_h[0] != d.h_samp || d.comp_v[0] != d.v_samp) { err = fmt("image %d: comp_h/v[0] must equal h_samp/v_samp", i); return PJD_E_ARG; }
+        for (int c = 0; c < d.num_components; c++) {
+            if (c > 0 && (d.comp_h[c] != 1 || d.comp_v[c] != 1)) { err = fmt("image %d: chroma sampling must be 1x1", i); return PJD_E_ARG; }
+            if (d.comp_qt[c] > 3 || d.comp_dc[c] > 3 || d.comp_ac[c] > 3) { err = fmt("image %d: table selector > 3", i); return PJD_E_ARG; }
+            if (!d.qt_set[d.comp_qt[c]] || !d.dc[d.comp_dc[c]].set || !d.ac[d.comp_ac[c]].set) { err = fmt("image %d: component uses an unset table", i); return PJD_E_ARG; }
+        }
+        if (d.ecs_len > 0 && !d.ecs) { err = fmt("image %d: null ecs", i); return PJD_E_ARG; }
+        if (d.ecs_len >= (1ull << 29)) { err = fmt("image %d: ecs larger than 512 MiB", i); return PJD_E_ARG; }
+
+        g.width = d.width; g.height = d.height;
+        g.ncomp = d.num_components; g.hs = d.h_samp; g.vs = d.v_samp;
+        g.n_luma = g.hs * g.vs;
+        g.dus_per_mcu = g.n_luma + g.ncomp - 1;
+        g.ref_mcu_w = (d.width + 7) / 8; g.ref_mcu_h = (d.height + 7) / 8;
+        g.ref_mcu_w_real = g.ref_mcu_w + ((g.hs == 2 && (g.ref_mcu_w & 1)) ? 1 : 0);
+        g.mcux = (g.ref_mcu_w + g.hs - 1) / g.hs;
+        g.mcuy = (g.ref_mcu_h + g.vs - 1) / g.vs;
+        g.n_mcu = g.mcux * g.mcuy;
+        g.restart_interval = d.restart_interval;
+        g.n_du = g.n_mcu * g.dus_per_mcu;
+        if (out_format == PJD_OUT_BMP) { g.flags |= PJD_IF_BMP; g.out_stride = d.width * 3 + d.width % 4; }
+        else g.out_stride = d.width * 3;
+        if (d.flags & PJD_F_STANDARD_RESTART) g.flags |= PJD_IF_STANDARD_RESTART;
+
+        // ---- quantisation tables: the reference copies QT t only while every t' < t is set
+        //      (decoder_host.cpp:173-178); later tables read as zero.  Only the low 16 bits of
+        //      a product survive the int16 store (decoder_dpu.c:169-172).
+        for (int c = 0; c < g.ncomp; c++) {
+            bool visible = true;
+            for (int t = 0; t <= d.comp_qt[c]; t++) visible = visible && d.qt_set[t];
+            for (int k = 0; k < 64; k++)
+                P.qtab[((size_t)i * 3 + c) * 64 + k] = visible ? (uint16_t)d.qt[d.comp_qt[c]][k] : 0;
+        }
+
+        // ---- Huffman tables: dedupe the (up to) 3 DC + 3 AC tables the components reference
+        int nt = 0;
+        const pjd_huff_table *seen[PJD_MAX_TABLES];
+        for (int c = 0; c < g.ncomp; c++)
+            for (int a = 0; a < 2; a++) {
+                const pjd_huff_table *t = a ? &d.ac[d.comp_ac[c]] : &d.dc[d.comp_dc[c]];
+                int s = -1;
+                for (int k = 0; k < nt; k++)
+                    if (P.tables[(size_t)i * PJD_MAX_TABLES + k].is_ac == a && same_table(*seen[k], *t)) { s = k; break; }
+                if (s < 0) {
+                    s = nt++;
+                    seen[s] = t;
+                    PjdDevHuffRaw &r = P.tables[(size_t)i * PJD_MAX_TABLES + s];
+                    std::memcpy(r.offsets, t->offsets, 17);
+                    std::memcpy(r.symbols, t->symbols, 162);
+                    r.is_ac = (uint8_t)a;
+                }
+                g.tbl_slot[c][a] = (uint8_t)s;
+            }
+        g.n_tables = (uint8_t)nt;
+
+        // ---- restart segments and routing
+        const uint32_t RI = d.restart_interval;
+        const bool luma11 = (g.hs == 1 && g.vs == 1);
+        const bool std_rule = (d.flags & PJD_F_STANDARD_RESTART) != 0;
+        bool sequential = (d.flags & PJD_F_FORCE_SEQUENTIAL) != 0;
+        uint32_t nseg_total = 1;
+        if (RI != 0) {
+            nseg_total = (g.n_mcu + RI - 1) / RI;
+            // the reference's rule (jpeg_scanner.cpp:723) equals the MCU counter only for 1x1 luma
+            if (!luma11 && !std_rule) sequential = true;
+            if (!d.seg_offsets || d.n_segments != nseg_total) sequential = true;
+        }
+        if (!sequential && d.seg_offsets) {
+            if (d.seg_offsets[0] != 0) sequential = true;
+            for (uint32_t k = 1; k < d.n_segments && !sequential; k++)
+                if (d.seg_offsets[k] < d.seg_offsets[k - 1] || d.seg_offsets[k] > d.ecs_len) sequential = true;
+        }
+        uint32_t seg_lo = 0, seg_hi = nseg_total;
+        if (d.shard_n_segs != 0) {
+            if (sequential || RI == 0) { err = fmt("image %d: sharding needs restart segments decodable by the parallel path", i); return PJD_E_ARG; }
+            if (d.shard_first_seg >= nseg_total || d.shard_first_seg + d.shard_n_segs > nseg_total) { err = fmt("image %d: shard out of range", i); return PJD_E_ARG; }
+            seg_lo = d.shard_first_seg; seg_hi = seg_lo + d.shard_n_segs;
+        }
+        h.sequential = sequential;
+        if (sequential) g.flags |= PJD_IF_SEQUENTIAL;
+
+        uint64_t byte_lo = 0, byte_hi = d.ecs_len;
+        if (RI != 0 && !sequential) {
+            byte_lo = d.seg_offsets[seg_lo];
+            byte_hi = (seg_hi < nseg_total) ? d.seg_offsets[seg_hi] : d.ecs_len;
+        }
+        g.first_mcu = (RI != 0 && !sequential) ? seg_lo * RI : 0;
+        g.last_mcu = (RI != 0 && !sequential && seg_hi < nseg_total) ? seg_hi * RI : g.n_mcu;
+
+        h.ecs_src = d.ecs ? d.ecs + byte_lo : nullptr;
+        h.ecs_copy_len = byte_hi - byte_lo;
+        g.ecs_len = (uint32_t)h.ecs_copy_len;
+        g.ecs_off = ecs_off;
+        ecs_off = align_up(ecs_off + h.ecs_copy_len + 16, 16);   // >= 16 zero bytes after every stream
+
+        g.seg_base = (uint32_t)P.segs.size();
+        g.sub_base = (uint32_t)P.subs.size();
+        g.hwg_base = (uint32_t)P.hwgs.size();
+        if (!sequential) {
+            for (uint32_t k = seg_lo; k < seg_hi; k++) {
+                PjdDevSegment s;
+                uint64_t b0 = (RI != 0) ? d.seg_offsets[k] : 0;
+                uint64_t b1 = (RI != 0 && k + 1 < nseg_total) ? d.seg_offsets[k + 1] : d.ecs_len;
+                s.byte_start = (uint32_t)(b0 - byte_lo);
+                s.byte_end = (uint32_t)(b1 - byte_lo);
+                uint32_t m0 = (RI != 0) ? k * RI : 0;
+                uint32_t m1 = (RI != 0) ? ((k + 1) * RI < g.n_mcu ? (k + 1) * RI : g.n_mcu) : g.n_mcu;
+                s.first_du = m0 * g.dus_per_mcu;
+                s.n_du = (m1 - m0) * g.dus_per_mcu;
+                const uint32_t seg_index = (uint32_t)P.segs.size();
+                P.segs.push_back(s);
+                uint32_t len = s.byte_end - s.byte_start;
+                uint32_t nsub = len ? (len + PJD_SUBSEQ_BYTES - 1) / PJD_SUBSEQ_BYTES : 1;
+                for (uint32_t j = 0; j < nsub; j++) {
+                    PjdDevSub q;
+                    q.byte_start = s.byte_start + j * PJD_SUBSEQ_BYTES;
+                    q.seg = seg_index | (j == 0 ? 0x80000000u : 0u);
+                    P.subs.push_back(q);
+                }
+            }
+            g.n_seg = (uint32_t)P.segs.size() - g.seg_base;
+            g.n_sub = (uint32_t)P.subs.size() - g.sub_base;
+            for (uint32_t s0 = 0; s0 < g.n_sub; s0 += PJD_HUFF_OWNED) {
+                PjdDevHuffWg w;
+                w.image = (uint32_t)i;
+                w.first_sub = g.sub_base + s0;
+                w.n_sub = (g.n_sub - s0 < PJD_HUFF_OWNED) ? g.n_sub - s0 : PJD_HUFF_OWNED;
+                w.pad_ = 0;
+                P.hwgs.push_back(w);
+            }
+            g.n_hwg = (uint32_t)P.hwgs.size() - g.hwg_base;
+            P.fast_images.push_back((uint32_t)i);
+        } else {
+            P.seq_images.push_back((uint32_t)i);
+        }
+
+        // ---- coefficient scratch, DC scan blocks, IDCT workgroups, output
+        g.du_base = du_base;
+        du_base += g.n_du;
+        g.dcblk_base = (uint32_t)dcblk;
+        g.n_dcblk = (g.n_mcu + PJD_DC_BLOCK - 1) / PJD_DC_BLOCK;
+        dcblk += g.n_dcblk;
+        const uint32_t per_wg = PJD_IDCT_MAX_DU / g.dus_per_mcu;
+        for (uint32_t m = g.first_mcu; m < g.last_mcu; m += per_wg) {
+            PjdDevIdctWg w;
+            w.image = (uint32_t)i;
+            w.first_mcu = m;
+            w.n_mcu = (g.last_mcu - m < per_wg) ? g.last_mcu - m : per_wg;
+            w.pad_ = 0;
+            P.iwgs.push_back(w);
+        }
+        h.out_bytes = pjd_output_size(d.width, d.height, out_format);
+        g.out_off = out_off;
+        out_off = align_up(out_off + h.out_bytes, 256);
+
+        P.pixels += (uint64_t)d.width * d.height;
+        P.ecs_bytes += d.ecs_len;
+        P.out_bytes += h.out_bytes;
+    }
+    P.ecs_buf_bytes = align_up(ecs_off + 256, 256);
+    P.n_du = du_base;
+    P.out_buf_bytes = align_up(out_off, 256);
+    P.n_dcblk = dcblk;
+    if (P.ecs_buf_bytes >= (1ull << 40)) { err = "batch bitstream too large"; return PJD_E_ARG; }
+    return PJD_OK;
+}

@@ -1,0 +1,36 @@
+// pjd_plan.h -- host-side batch planner: pjd_image_desc[] -> device work lists.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/pjd.h"
+#include "pjd_internal.h"
+
+struct PjdHostImage {
+    const uint8_t *ecs_src;     // caller memory: first byte to upload
+    uint64_t ecs_copy_len;      // bytes to upload
+    uint64_t out_bytes;         // size of this picture in the chosen output format
+    bool sequential;            // routed to the exact one-lane kernel up front
+};
+
+struct PjdPlan {
+    int out_format = 0;
+    std::vector<PjdDevImage> images;
+    std::vector<PjdHostImage> host;
+    std::vector<PjdDevHuffRaw> tables;     // n_images * PJD_MAX_TABLES
+    std::vector<uint16_t> qtab;            // n_images * 3 * 64, natural order, low 16 bits
+    std::vector<PjdDevSegment> segs;
+    std::vector<PjdDevSub> subs;
+    std::vector<PjdDevHuffWg> hwgs;
+    std::vector<PjdDevIdctWg> iwgs;
+    std::vector<uint32_t> seq_images;      // indices of `sequential` images
+    std::vector<uint32_t> fast_images;     // the others
+    uint64_t ecs_buf_bytes = 0;            // size of the packed bitstream buffer (incl. padding)
+    uint64_t n_du = 0;                     // data units in the coefficient buffer
+    uint64_t out_buf_bytes = 0;
+    uint64_t n_dcblk = 0;
+    uint64_t pixels = 0, ecs_bytes = 0, out_bytes = 0;
+};
+
+// Returns PJD_OK or PJD_E_ARG (with a message in `err`).
+int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &plan, std::string &err);

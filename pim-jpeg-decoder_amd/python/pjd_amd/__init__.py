@@ -1,0 +1,308 @@
+"""pjd_amd -- thin ctypes binding of the C ABI in include/pjd.h and include/pjd_host.h.
+
+Python is plumbing here (tests, bench harness); the product is lib/libpjd.so (HIP kernels for
+gfx950 behind the C ABI) and lib/libpjdhost.so (scanner + BMP helpers).  There is no CPU decode
+path in this package: without a gfx950 device `Context()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_DIR = os.path.join(_PKG, "lib")
+LIBPJD = os.path.join(LIB_DIR, "libpjd.so")
+LIBHOST = os.path.join(LIB_DIR, "libpjdhost.so")
+
+OUT_RGB8, OUT_BMP = 0, 1
+F_STANDARD_RESTART, F_FORCE_SEQUENTIAL = 1, 2
+MAX_KERNELS = 16
+
+
+class HuffTable(C.Structure):
+    _fields_ = [("offsets", C.c_uint8 * 17), ("symbols", C.c_uint8 * 162), ("set", C.c_uint8)]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("num_components", C.c_uint8), ("h_samp", C.c_uint8), ("v_samp", C.c_uint8),
+        ("comp_h", C.c_uint8 * 3), ("comp_v", C.c_uint8 * 3),
+        ("comp_qt", C.c_uint8 * 3), ("comp_dc", C.c_uint8 * 3), ("comp_ac", C.c_uint8 * 3),
+        ("qt_set", C.c_uint8 * 4),
+        ("qt", (C.c_uint32 * 64) * 4),
+        ("dc", HuffTable * 4), ("ac", HuffTable * 4),
+        ("restart_interval", C.c_uint32),
+        ("ecs", C.c_void_p), ("ecs_len", C.c_uint64),
+        ("seg_offsets", C.c_void_p), ("n_segments", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("shard_first_seg", C.c_uint32), ("shard_n_segs", C.c_uint32),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [("n", C.c_int32), ("ms", C.c_float * MAX_KERNELS),
+                ("name", (C.c_char * 32) * MAX_KERNELS), ("total_ms", C.c_float)]
+
+    def as_dict(self):
+        return {self.name[i].value.decode(): float(self.ms[i]) for i in range(self.n)}
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [("n_images", C.c_int32), ("pixels", C.c_uint64), ("ecs_bytes", C.c_uint64),
+                ("out_bytes", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_data_units", C.c_uint64),
+                ("n_subsequences", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("n_sequential", C.c_int32), ("n_fallback", C.c_int32)]
+
+
+class PjdError(RuntimeError):
+    pass
+
+
+_host = None
+_dev = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(LIBHOST):
+            raise PjdError(f"{LIBHOST} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIBHOST)
+        L.pjd_scan_memory.restype = C.c_int
+        L.pjd_scan_memory.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.pjd_scan_file.restype = C.c_int
+        L.pjd_scan_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.pjd_scanned_desc.restype = C.POINTER(ImageDesc)
+        L.pjd_scanned_desc.argtypes = [C.c_void_p]
+        L.pjd_scanned_log.restype = C.c_char_p
+        L.pjd_scanned_log.argtypes = [C.c_void_p]
+        L.pjd_scanned_valid.restype = C.c_int
+        L.pjd_scanned_valid.argtypes = [C.c_void_p]
+        L.pjd_scanned_free.argtypes = [C.c_void_p]
+        L.pjd_scanned_metadata.argtypes = [C.c_void_p, C.c_void_p]
+        L.pjd_rgb_to_bmp.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.pjd_write_file.restype = C.c_int
+        L.pjd_write_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
+        _host = L
+    return _host
+
+
+def dev_lib():
+    """Load libpjd.so.  Fails loudly when the HIP extension has not been built."""
+    global _dev
+    if _dev is None:
+        if not os.path.exists(LIBPJD):
+            raise PjdError(f"{LIBPJD} missing: the HIP extension is not built (no CPU fallback exists)")
+        L = C.CDLL(LIBPJD)
+        vp, i32 = C.c_void_p, C.c_int
+        L.pjd_version.restype = i32
+        L.pjd_open.restype = i32
+        L.pjd_open.argtypes = [i32, C.POINTER(vp)]
+        L.pjd_close.argtypes = [vp]
+        L.pjd_last_error.restype = C.c_char_p
+        L.pjd_last_error.argtypes = [vp]
+        L.pjd_status_string.restype = C.c_char_p
+        L.pjd_status_string.argtypes = [i32]
+        L.pjd_stream.restype = vp
+        L.pjd_stream.argtypes = [vp]
+        L.pjd_batch_create.restype = i32
+        L.pjd_batch_create.argtypes = [vp, C.POINTER(ImageDesc), i32, i32, C.POINTER(vp)]
+        for fn in ("pjd_batch_upload", "pjd_batch_decode", "pjd_batch_capture", "pjd_batch_sync"):
+            getattr(L, fn).restype = i32
+            getattr(L, fn).argtypes = [vp]
+        L.pjd_batch_decode_timed.restype = i32
+        L.pjd_batch_decode_timed.argtypes = [vp, C.POINTER(Timings)]
+        L.pjd_batch_download.restype = i32
+        L.pjd_batch_download.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32)]
+        L.pjd_batch_get_info.restype = i32
+        L.pjd_batch_get_info.argtypes = [vp, C.POINTER(BatchInfo)]
+        L.pjd_batch_output_size.restype = C.c_uint64
+        L.pjd_batch_output_size.argtypes = [vp, i32]
+        L.pjd_batch_device_output.restype = vp
+        L.pjd_batch_device_output.argtypes = [vp, i32]
+        L.pjd_batch_device_status.restype = vp
+        L.pjd_batch_device_status.argtypes = [vp]
+        L.pjd_batch_destroy.argtypes = [vp]
+        L.pjd_decode_batch.restype = i32
+        L.pjd_decode_batch.argtypes = [vp, C.POINTER(ImageDesc), i32, i32, C.POINTER(vp), C.POINTER(C.c_int32)]
+        L.pjd_exec_dpu_payload.restype = i32
+        L.pjd_exec_dpu_payload.argtypes = [vp, vp, vp, i32]
+        L.pjd_output_size.restype = C.c_uint64
+        L.pjd_output_size.argtypes = [C.c_uint32, C.c_uint32, i32]
+        L.pjd_plan_info.restype = i32
+        L.pjd_plan_info.argtypes = [C.POINTER(ImageDesc), i32, i32, C.POINTER(BatchInfo)]
+        _dev = L
+    return _dev
+
+
+class Scanned:
+    """A parsed JPEG (host side).  Mirrors the reference's `Header` for the decode path."""
+
+    def __init__(self, data: bytes = None, name: str = "x.jpg", path: str = None):
+        L = host_lib()
+        h = C.c_void_p()
+        if path is not None:
+            rc = L.pjd_scan_file(path.encode(), C.byref(h))
+            if rc == 2:
+                raise FileNotFoundError(path)
+        else:
+            self._data = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+            rc = L.pjd_scan_memory(self._data.ctypes.data, len(data), name.encode(), C.byref(h))
+        self._h = h
+        self.rc = rc
+        self.valid = bool(L.pjd_scanned_valid(h))
+        self.log = L.pjd_scanned_log(h).decode()
+        self.desc = L.pjd_scanned_desc(h).contents
+
+    def metadata(self):
+        m = np.zeros(276, np.uint32)
+        host_lib().pjd_scanned_metadata(self._h, m.ctypes.data)
+        return m
+
+    def ecs(self):
+        n = int(self.desc.ecs_len)
+        if n == 0:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(C.cast(self.desc.ecs, C.POINTER(C.c_uint8)), (n,)).copy()
+
+    def seg_offsets(self):
+        n = int(self.desc.n_segments)
+        return np.ctypeslib.as_array(C.cast(self.desc.seg_offsets, C.POINTER(C.c_uint64)), (n,)).copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                host_lib().pjd_scanned_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def rgb_to_bmp(rgb: np.ndarray) -> bytes:
+    h, w, _ = rgb.shape
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    out = np.zeros(26 + h * (3 * w + w % 4), np.uint8)
+    host_lib().pjd_rgb_to_bmp(rgb.ctypes.data, w, h, out.ctypes.data)
+    return out.tobytes()
+
+
+class Context:
+    """One GPU (replaces DpuSet::allocate + load of the reference)."""
+
+    def __init__(self, device: int = 0):
+        L = dev_lib()
+        h = C.c_void_p()
+        rc = L.pjd_open(device, C.byref(h))
+        if rc != 0:
+            raise PjdError(f"pjd_open({device}) failed with {rc}: no usable gfx950 device")
+        self._h = h
+        self.L = L
+
+    def close(self):
+        if self._h:
+            self.L.pjd_close(self._h)
+            self._h = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PjdError(f"{what} failed ({rc}): {self.L.pjd_last_error(self._h).decode()}")
+
+    @property
+    def stream(self):
+        return self.L.pjd_stream(self._h)
+
+    def batch(self, descs, out_format=OUT_RGB8):
+        return Batch(self, descs, out_format)
+
+    def decode(self, descs, out_format=OUT_RGB8):
+        """One-shot decode -> (list of np.uint8 arrays, list of status ints)."""
+        with self.batch(descs, out_format) as b:
+            b.upload()
+            b.decode()
+            return b.download()
+
+    def exec_dpu_payload(self, metadata: np.ndarray, mcus: np.ndarray):
+        """The literal DPU contract: metadata (n,276) uint32, mcus (n,19200) int16 in/out."""
+        metadata = np.ascontiguousarray(metadata, np.uint32).reshape(-1, 276)
+        assert mcus.dtype == np.int16 and mcus.flags.c_contiguous
+        n = metadata.shape[0]
+        assert mcus.size == n * 19200
+        self._check(self.L.pjd_exec_dpu_payload(self._h, metadata.ctypes.data, mcus.ctypes.data, n), "pjd_exec_dpu_payload")
+        return mcus
+
+
+class Batch:
+    def __init__(self, ctx: Context, descs, out_format):
+        self.ctx, self.L = ctx, ctx.L
+        self.n = len(descs)
+        self.out_format = out_format
+        arr = (ImageDesc * max(self.n, 1))()
+        for i, d in enumerate(descs):
+            C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(ImageDesc))
+        self._descs = arr
+        self._keep = descs
+        h = C.c_void_p()
+        ctx._check(self.L.pjd_batch_create(ctx._h, arr, self.n, out_format, C.byref(h)), "pjd_batch_create")
+        self._h = h
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.destroy()
+
+    def destroy(self):
+        if self._h:
+            self.L.pjd_batch_destroy(self._h)
+            self._h = None
+
+    def upload(self):
+        self.ctx._check(self.L.pjd_batch_upload(self._h), "pjd_batch_upload")
+
+    def decode(self):
+        self.ctx._check(self.L.pjd_batch_decode(self._h), "pjd_batch_decode")
+
+    def decode_timed(self):
+        t = Timings()
+        self.ctx._check(self.L.pjd_batch_decode_timed(self._h, C.byref(t)), "pjd_batch_decode_timed")
+        return t.as_dict(), float(t.total_ms)
+
+    def capture(self):
+        self.ctx._check(self.L.pjd_batch_capture(self._h), "pjd_batch_capture")
+
+    def sync(self):
+        self.ctx._check(self.L.pjd_batch_sync(self._h), "pjd_batch_sync")
+
+    def info(self):
+        bi = BatchInfo()
+        self.ctx._check(self.L.pjd_batch_get_info(self._h, C.byref(bi)), "pjd_batch_get_info")
+        return {k: int(getattr(bi, k)) for k, _ in bi._fields_}
+
+    def output_size(self, i):
+        return int(self.L.pjd_batch_output_size(self._h, i))
+
+    def device_output(self, i):
+        return self.L.pjd_batch_device_output(self._h, i)
+
+    def download(self):
+        outs = [np.zeros(self.output_size(i), np.uint8) for i in range(self.n)]
+        ptrs = (C.c_void_p * max(self.n, 1))(*[o.ctypes.data for o in outs])
+        st = (C.c_int32 * max(self.n, 1))()
+        self.ctx._check(self.L.pjd_batch_download(self._h, ptrs, st), "pjd_batch_download")
+        if self.out_format == OUT_RGB8:
+            outs = [o.reshape(int(self._descs[i].height), int(self._descs[i].width), 3) for i, o in enumerate(outs)]
+        return outs, [int(st[i]) for i in range(self.n)]
+
+
+def plan_info(descs, out_format=OUT_RGB8):
+    """Host-only: what a batch of these images would occupy (no GPU needed)."""
+    L = dev_lib()
+    arr = (ImageDesc * max(len(descs), 1))()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(ImageDesc))
+    bi = BatchInfo()
+    rc = L.pjd_plan_info(arr, len(descs), out_format, C.byref(bi))
+    if rc != 0:
+        raise PjdError(f"pjd_plan_info failed ({rc})")
+    return {k: int(getattr(bi, k)) for k, _ in bi._fields_}

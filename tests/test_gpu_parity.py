@@ -1,0 +1,141 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, through the C ABI, against the
+oracle (oracle/liboracle.so, pinned to the reference in test_oracle.py) and against the golden
+manifest generated from the reference's own code.  Bit-exact everywhere: this is integer work."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_bytes
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MANIFEST = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
+VALID = sorted(k for k, v in MANIFEST.items() if v["rc"] == 0)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import pjd_amd
+    c = pjd_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _desc(name, flags=0):
+    import pjd_amd
+    s = pjd_amd.Scanned(golden_bytes(name))
+    assert s.valid
+    s.desc.flags = flags
+    return s
+
+
+# ---- the literal DPU contract -------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ilsvrc_val_00000001", "env_61x45_420_q85_opt", "env_72x40_422_q100", "h1v2_45x61",
+                                  "gray_61x45", "noise_96x80_444_q100", "dqt16_64x48_444", "err_truncated_eoi_420"])
+def test_dpu_payload_matches_oracle(ctx, port, name):
+    if name not in MANIFEST:
+        pytest.skip("fixture renamed")
+    o = port.decode(golden_bytes(name))
+    n = o["coef"].shape[0]
+    meta = np.tile(o["metadata"], (n, 1))
+    mcus = o["coef"].copy()
+    ctx.exec_dpu_payload(meta, mcus)
+    assert np.array_equal(mcus, o["mcus"])
+
+
+def test_dpu_payload_random_blocks(ctx, port):
+    """Random coefficient blocks and quantisation tables, all four sampling modes, 1-3 components:
+    exercises int16 wrap in dequant / IDCT and the colour clamps far outside encoder ranges."""
+    rng = np.random.default_rng(1234)
+    for V, H in ((1, 1), (2, 1), (1, 2), (2, 2)):
+        for ncomp in (1, 2, 3):
+            n = 3
+            meta = np.zeros(276, np.uint32)
+            meta[4], meta[5], meta[6], meta[19] = ncomp, V, H, 100
+            meta[7:7 + ncomp] = rng.integers(0, 4, ncomp)
+            meta[20:] = rng.integers(1, 70000, 256)
+            amp = int(rng.choice([40, 1200, 32767]))
+            coef = rng.integers(-amp, amp + 1, (n, 19200)).astype(np.int16)
+            want = coef.copy()
+            for d in range(n):
+                port.dpu_exec(meta, want[d])
+            got = coef.copy()
+            ctx.exec_dpu_payload(np.tile(meta, (n, 1)), got)
+            assert np.array_equal(got, want), (V, H, ncomp)
+
+
+# ---- the whole path: JPEG bytes -> pictures -------------------------------------------------
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("name", VALID)
+def test_decode_rgb_matches_oracle(ctx, port, name, mode):
+    import pjd_amd
+    s = _desc(name, pjd_amd.F_FORCE_SEQUENTIAL if mode == "exact" else 0)
+    o = port.decode(golden_bytes(name))
+    outs, st = ctx.decode([s.desc], pjd_amd.OUT_RGB8)
+    assert st[0] == o["huff_rc"]
+    diff = np.argwhere(outs[0] != o["rgb"])
+    assert diff.size == 0, f"{len(diff)} samples differ, first at {diff[0] if len(diff) else None}"
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_decode_bmp_batch_matches_reference_hashes(ctx, mode):
+    """All decodable fixtures in ONE batch, BMP output, against hashes from the reference's code."""
+    import pjd_amd
+    flags = pjd_amd.F_FORCE_SEQUENTIAL if mode == "exact" else 0
+    scanned = [_desc(n, flags) for n in VALID]
+    outs, st = ctx.decode([s.desc for s in scanned], pjd_amd.OUT_BMP)
+    for name, bmp, status in zip(VALID, outs, st):
+        ent = MANIFEST[name]
+        assert len(bmp) == ent["bmp_len"], name
+        assert hashlib.sha256(bmp.tobytes()).hexdigest() == ent["bmp_sha256"], name
+        assert (status == 0) == bool(ent["huff_ok"]), name
+
+
+def test_known_answer_config1(ctx):
+    """BASELINE config #1: the bundled ImageNet sample -> the SURVEY section 0.4 BMP."""
+    import pjd_amd
+    s = _desc("ilsvrc_val_00000001")
+    outs, st = ctx.decode([s.desc], pjd_amd.OUT_BMP)
+    assert st == [0]
+    assert hashlib.sha256(outs[0].tobytes()).hexdigest() == "11ab0c81cfc918410245c5ff0923f787219521073c094cbfd7e763f4b3444c1f"
+    assert hashlib.md5(outs[0].tobytes()).hexdigest() == "fa708c3f78f341909052666db44586d2"
+
+
+def test_repeat_decode_and_graph_replay_are_idempotent(ctx, port):
+    import pjd_amd
+    names = ["big_640x480_420_q85", "ilsvrc_val_00000001", "rstrow_200x150_444_opt", "gray_33x70"]
+    names = [n for n in names if n in MANIFEST]
+    scanned = [_desc(n) for n in names]
+    want = [port.decode(golden_bytes(n))["rgb"] for n in names]
+    with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8) as b:
+        b.upload()
+        for _ in range(3):
+            b.decode()
+        outs, st = b.download()
+        for w, g in zip(want, outs):
+            assert np.array_equal(w, g)
+        b.capture()
+        for _ in range(3):
+            b.decode()
+        outs, st = b.download()
+        for w, g in zip(want, outs):
+            assert np.array_equal(w, g)
+        times, total = b.decode_timed()
+        assert total > 0 and "idct_colour" in times
+        info = b.info()
+        assert info["n_images"] == len(names) and info["pixels"] == sum(w.shape[0] * w.shape[1] for w in want)
+
+
+def test_empty_batch_and_bad_descriptor(ctx):
+    import pjd_amd
+    outs, st = ctx.decode([], pjd_amd.OUT_RGB8)
+    assert outs == [] and st == []
+    s = _desc("gray_61x45")
+    s.desc.num_components = 4
+    with pytest.raises(pjd_amd.PjdError):
+        ctx.decode([s.desc])

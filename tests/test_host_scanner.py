@@ -1,0 +1,123 @@
+"""CPU tests of the product's host scanner / BMP helper (libpjdhost.so) against the oracle,
+and of the C-ABI libraries' export tables.  No GPU needed, no compute calls."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import golden_bytes, ROOT
+
+import pjd_amd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAMES = sorted(json.load(open(os.path.join(HERE, "golden", "manifest.json"))).keys())
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_scanner_matches_oracle(port, manifest, name):
+    data = golden_bytes(name)
+    s = pjd_amd.Scanned(data, name="{path}")
+    o = port.parse(data, name="{path}")
+    ent = manifest[name]
+    assert s.valid == bool(o["info"]["valid"]) == (ent["rc"] == 0)
+    if not s.valid:
+        # rejected files: same messages as the reference (the manifest's stdout comes from it)
+        assert s.log == ent["stdout"]
+        return
+    assert s.log == ""
+    d, i = s.desc, o["info"]
+    assert (d.width, d.height, d.num_components, d.h_samp, d.v_samp) == (i["width"], i["height"], i["ncomp"], i["hsamp"], i["vsamp"])
+    assert d.restart_interval == i["restart_interval"]
+    n = d.num_components
+    for f, g in (("comp_h", "comp_h"), ("comp_v", "comp_v"), ("comp_qt", "comp_qt"), ("comp_dc", "comp_dc"), ("comp_ac", "comp_ac")):
+        assert list(getattr(d, f))[:n] == i[g][:n], f
+    assert list(d.qt_set) == i["qt_set"]
+    for t in range(4):
+        if i["qt_set"][t]:
+            assert list(d.qt[t]) == i["qt"][t]
+        assert d.dc[t].set == i["dc_set"][t] and d.ac[t].set == i["ac_set"][t]
+        if i["dc_set"][t]:
+            assert list(d.dc[t].offsets) == i["dc_offsets"][t]
+            k = i["dc_offsets"][t][16]
+            assert list(d.dc[t].symbols)[:k] == i["dc_symbols"][t][:k]
+        if i["ac_set"][t]:
+            assert list(d.ac[t].offsets) == i["ac_offsets"][t]
+            k = i["ac_offsets"][t][16]
+            assert list(d.ac[t].symbols)[:k] == i["ac_symbols"][t][:k]
+    assert np.array_equal(s.ecs(), o["ecs"])
+    assert np.array_equal(s.metadata(), o["metadata"])
+    segs = s.seg_offsets()
+    assert segs[0] == 0 and np.all(np.diff(segs.astype(np.int64)) >= 0) and segs[-1] <= d.ecs_len
+
+
+def test_segment_offsets_are_restart_boundaries(port):
+    """Each recorded offset is where the reference's BitReader stands after align()."""
+    for name in ("rst4_128x96_444", "rstrow_200x150_444_opt", "rst7_gray_61x45", "rst1_61x45_444"):
+        data = golden_bytes(name)
+        s = pjd_amd.Scanned(data)
+        d = s.desc
+        mcux = (d.width + 8 * d.h_samp - 1) // (8 * d.h_samp)
+        mcuy = (d.height + 8 * d.v_samp - 1) // (8 * d.v_samp)
+        assert d.n_segments == -(-mcux * mcuy // d.restart_interval)
+        # raw file: count RSTn markers in the scan
+        raw = np.frombuffer(data, np.uint8)
+        n_rst = sum(1 for i in range(len(raw) - 1) if raw[i] == 0xFF and 0xD0 <= raw[i + 1] <= 0xD7)
+        assert d.n_segments == n_rst + 1
+
+
+def test_rgb_to_bmp_matches_oracle(port):
+    for name in ("env_61x45_444_q30_opt", "env_17x9_420_q100", "ilsvrc_val_00000001"):
+        if name not in NAMES:
+            continue
+        o = port.decode(golden_bytes(name))
+        assert pjd_amd.rgb_to_bmp(o["rgb"]) == o["bmp"]
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pjd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _exported(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def test_libpjd_exports_every_declared_symbol():
+    names = _declared("pjd.h")
+    assert "pjd_batch_decode" in names and "pjd_exec_dpu_payload" in names
+    exp = _exported(pjd_amd.LIBPJD)
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+    L = pjd_amd.dev_lib()          # loads (no compute call)
+    assert L.pjd_version() == 1
+    assert L.pjd_output_size(500, 375, pjd_amd.OUT_BMP) == 562526
+    assert L.pjd_output_size(61, 45, pjd_amd.OUT_BMP) == 26 + 45 * (183 + 1)
+
+
+def test_libpjdhost_exports_every_declared_symbol():
+    names = [n for n in _declared("pjd_host.h") if n not in _declared("pjd.h")]
+    exp = _exported(pjd_amd.LIBHOST)
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+
+
+def test_plan_info_host_only():
+    """The planner runs without a device: lanes, data units, routing."""
+    descs, keep = [], []
+    for name in ("ilsvrc_val_00000001", "big_640x480_420_q85", "rstrow_200x150_444_opt", "div_rst_420_64x48", "gray_61x45"):
+        s = pjd_amd.Scanned(golden_bytes(name))
+        keep.append(s)
+        descs.append(s.desc)
+    info = pjd_amd.plan_info(descs)
+    assert info["n_images"] == 5
+    assert info["pixels"] == 500 * 375 + 640 * 480 + 200 * 150 + 64 * 48 + 61 * 45
+    # 4:4:4 -> 3 units per 8x8; 4:2:0 -> 6 per 16x16; grey -> 1 per 8x8
+    assert info["n_data_units"] == 63 * 47 * 3 + 40 * 30 * 6 + 25 * 19 * 3 + 4 * 3 * 6 + 8 * 6
+    assert info["n_sequential"] == 1          # 4:2:0 + DRI under the reference's restart rule
+    assert info["n_subsequences"] >= (info["ecs_bytes"] - 3000) // 128
