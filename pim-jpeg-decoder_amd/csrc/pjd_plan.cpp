@@ -62,6 +62,13 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             if (d.comp_qt[c] > 3 || d.comp_dc[c] > 3 || d.comp_ac[c] > 3) { err = fmt("image %d: table selector > 3", i); return PJD_E_ARG; }
             if (!d.qt_set[d.comp_qt[c]] || !d.dc[d.comp_dc[c]].set || !d.ac[d.comp_ac[c]].set) { err = fmt("image %d: component uses an unset table", i); return PJD_E_ARG; }
         }
+        for (int c = 0; c < d.num_components; c++)
+            for (int a = 0; a < 2; a++) {
+                const pjd_huff_table &t = a ? d.ac[d.comp_ac[c]] : d.dc[d.comp_dc[c]];
+                bool ok = t.offsets[0] == 0 && t.offsets[16] <= 162;
+                for (int k = 1; k <= 16; k++) ok = ok && t.offsets[k] >= t.offsets[k - 1];
+                if (!ok) { err = fmt("image %d: malformed Huffman table offsets", i); return PJD_E_ARG; }
+            }
         if (d.ecs_len > 0 && !d.ecs) { err = fmt("image %d: null ecs", i); return PJD_E_ARG; }
         if (d.ecs_len >= (1ull << 29)) { err = fmt("image %d: ecs larger than 512 MiB", i); return PJD_E_ARG; }
 
