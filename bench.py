@@ -190,7 +190,8 @@ def main():
             "config": {"workload": f"{args.workload}: {label}", "images_per_gpu": info["n_images"],
                        "pixels_per_gpu": pixels, "ecs_bytes_per_gpu": info["ecs_bytes"],
                        "huffman_lanes": info["n_subsequences"], "exact_kernel_images": info["n_sequential"] + info["n_fallback"],
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": not args.no_graph,
+                       "sync": {k: info[k] for k in ("n_huff_workgroups", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes")}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(ktimes[dom], 4)},

@@ -127,6 +127,11 @@ typedef struct pjd_batch_info {
     uint64_t device_bytes;             /* everything this batch holds in HBM                  */
     int32_t  n_sequential;             /* images routed to the exact one-lane kernel up front */
     int32_t  n_fallback;               /* images re-decoded by it after the last decode       */
+    uint64_t n_huff_workgroups;        /* Huffman workgroups (255 lanes each)                 */
+    /* diagnostics of the last decode: self-synchronisation effort                           */
+    uint64_t sync_rounds;              /* re-sync rounds summed over workgroups               */
+    uint64_t sync_lane_passes;         /* lanes that re-decoded their subsequence, summed     */
+    uint64_t fix_rounds, fix_lane_passes;   /* the same for the boundary-stitch kernel        */
 } pjd_batch_info;
 
 /* ---- context --------------------------------------------------------------- */

@@ -151,7 +151,7 @@ void pjd_batch_destroy(pjd_batch *b)
     void *ptrs[] = { b->d_images, b->d_raw, b->d_qtab, b->d_segs, b->d_subs, b->d_hwgs, b->d_iwgs, b->d_ecs,
                      b->d_dcblk_image, b->d_seq_list, b->d_fb_list, b->d_fb_iwgs, b->d_status_init,
                      b->dev.luts, b->dev.coef, b->dev.out, b->dev.status, b->dev.sub_exit, b->dev.sub_cnt,
-                     b->dev.wg_entry, b->dev.wg_exit, b->dev.wg_agg, b->dev.wg_du_in, b->dev.dc_agg, b->dev.dc_carry };
+                     b->dev.wg_entry, b->dev.wg_exit, b->dev.wg_agg, b->dev.wg_du_in, b->dev.dc_agg, b->dev.dc_carry, b->dev.stats };
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->h_ecs) hipHostFree(b->h_ecs);
     if (b->h_status) hipHostFree(b->h_status);
@@ -213,6 +213,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.wg_du_in, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_agg, P.n_dcblk * 4, tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_carry, P.n_dcblk * 4, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.stats, 8, tot));
 #undef TRY_RC
     b->dev.images = b->d_images; b->dev.raw_tables = b->d_raw; b->dev.qtab = b->d_qtab;
     b->dev.segs = b->d_segs; b->dev.subs = b->d_subs; b->dev.hwgs = b->d_hwgs; b->dev.iwgs = b->d_iwgs;
@@ -302,6 +303,7 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     kt.mark("start");
     HIP_TRY(ctx, hipMemcpyAsync(b->dev.status, b->d_status_init, sizeof(int32_t) * P.images.size(), hipMemcpyDeviceToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, P.n_du * 64 * sizeof(int16_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->dev.stats, 0, 8 * sizeof(unsigned long long), s));
     kt.mark("memset_coef");
     if (parallel) {
         pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
@@ -446,6 +448,11 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     info->device_bytes = b->device_bytes;
     info->n_sequential = (int32_t)b->seq_list.size();
     info->n_fallback = b->n_fallback;
+    unsigned long long st[8] = {0};
+    if (b->decoded && hipMemcpy(st, b->dev.stats, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+        info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
+    }
+    info->n_huff_workgroups = P.hwgs.size();
     return PJD_OK;
 }
 

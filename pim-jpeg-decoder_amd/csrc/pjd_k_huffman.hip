@@ -79,7 +79,9 @@ struct HuffLds {
     __attribute__((aligned(4))) uint8_t tabs[PJD_MAX_TABLES * LUT_BYTES];
 };
 
-struct LaneTables { uint32_t dc0, ac0, dc1, ac1, dc2, ac2; };         // byte offsets into HuffLds::tabs
+// table slot (0..5) of {DC,AC} x component, 4 bits each: bits [4*(2*comp+is_ac) +: 4].  One register,
+// selected arithmetically -- a struct of six offsets gets demoted to scratch memory by the compiler.
+struct LaneTables { uint32_t packed; };
 
 __device__ __forceinline__ uint32_t stream_dword(const uint32_t *s, uint32_t d) { return s[d + (d >> 5)]; }
 
@@ -117,7 +119,8 @@ __device__ __forceinline__ void decode_span(const HuffLds &L, const LaneTables &
     while (p < end_bit && (!WRITE || D < D_end)) {
         const uint32_t pk = w.peek(L.stream);
         const bool is_dc = (z == 0);
-        const uint32_t tb = c < nl ? (is_dc ? T.dc0 : T.ac0) : (c == nl ? (is_dc ? T.dc1 : T.ac1) : (is_dc ? T.dc2 : T.ac2));
+        const uint32_t comp = (c >= nl ? 1u : 0u) + (c > nl ? 1u : 0u);
+        const uint32_t tb = ((T.packed >> (8 * comp + (is_dc ? 0u : 4u))) & 15u) * LUT_BYTES;
         const uint8_t *tab = L.tabs + tb;
         const uint32_t e = *reinterpret_cast<const uint16_t *>(tab + 2 * (pk >> (32 - PJD_LUT_BITS)));
         uint32_t len = e >> 8, sym = e & 255;
@@ -205,9 +208,9 @@ __device__ __forceinline__ void wg_setup(const PjdDevBatch &B, const PjdDevHuffW
         g.end_bit = (end_byte - lo16) * 8;
         g.seg_end_bit = (sg.byte_end - lo16) * 8;
     }
-    T.dc0 = im.tbl_slot[0][0] * LUT_BYTES; T.ac0 = im.tbl_slot[0][1] * LUT_BYTES;
-    T.dc1 = im.tbl_slot[1][0] * LUT_BYTES; T.ac1 = im.tbl_slot[1][1] * LUT_BYTES;
-    T.dc2 = im.tbl_slot[2][0] * LUT_BYTES; T.ac2 = im.tbl_slot[2][1] * LUT_BYTES;
+    T.packed = 0;
+    for (int cc = 0; cc < 3; cc++)
+        T.packed |= ((uint32_t)im.tbl_slot[cc][0] << (8 * cc)) | ((uint32_t)im.tbl_slot[cc][1] << (8 * cc + 4));
     if (!stage) return;
     // bitstream: [lo16, end of the last owned subsequence + 16), 16 B per lane per step
     const PjdDevSub last = B.subs[wg.first_sub + wg.n_sub - 1];
@@ -237,7 +240,8 @@ __device__ __forceinline__ void wg_setup(const PjdDevBatch &B, const PjdDevHuffW
 // whenever E[t-1] changed in the previous round.  Returns false if the cap was hit.
 __device__ __forceinline__ bool resync_rounds(const HuffLds &L, const LaneTables &T, const LaneGeom &g,
                                               uint32_t nl, uint32_t dus,
-                                              uint32_t *Ep, uint32_t *Ecz, uint32_t *Ecnt, uint32_t *chg /*[2][256]*/)
+                                              uint32_t *Ep, uint32_t *Ecz, uint32_t *Ecnt, uint32_t *chg /*[2][256]*/,
+                                              unsigned long long *stats, int stat_base)
 {
     const uint32_t t = threadIdx.x;
     int cur = 0;
@@ -246,6 +250,8 @@ __device__ __forceinline__ bool resync_rounds(const HuffLds &L, const LaneTables
         uint32_t p = 0, c = 0, z = 0;
         if (act) { p = Ep[t - 1]; const uint32_t cz = Ecz[t - 1]; c = cz >> 8; z = cz & 255; }
         __syncthreads();
+        if (act && stats) atomicAdd(stats + stat_base + 1, 1ull);
+        if (threadIdx.x == 0 && stats) atomicAdd(stats + stat_base, 1ull);
         uint32_t changed = 0;
         if (act) {
             uint32_t ndu = 0, err = 0, D = 0;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_sync(PjdDevBatch 
     Ep[t] = p; Ecz[t] = (c << 8) | z; Ecnt[t] = ndu;
     chg[t] = g.valid ? 1 : 0;
     __syncthreads();
-    const bool ok = resync_rounds(L, T, g, nl, dus, Ep, Ecz, Ecnt, chg);
+    const bool ok = resync_rounds(L, T, g, nl, dus, Ep, Ecz, Ecnt, chg, B.stats, 0);
     if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
 
     if (g.owned) {
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_fix(PjdDevBatch B
         Ecnt[t] = g.owned ? B.sub_cnt[g.q] : 0;
         chg[t] = (t == 0) ? 1 : 0;
         __syncthreads();
-        const bool ok = resync_rounds(L, T, g, im.n_luma, im.dus_per_mcu, Ep, Ecz, Ecnt, chg);
+        const bool ok = resync_rounds(L, T, g, im.n_luma, im.dus_per_mcu, Ep, Ecz, Ecnt, chg, B.stats, 2);
         if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
         if (g.owned) {
             B.sub_exit[g.q] = pjd_pack_state(Ep[t] + g.base_bit, Ecz[t] >> 8, Ecz[t] & 255);

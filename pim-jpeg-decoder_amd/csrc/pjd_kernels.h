@@ -30,6 +30,7 @@ struct PjdDevBatch {
     uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
     uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
     const uint32_t *dcblk_image;         // per DC block: owning image
+    unsigned long long *stats;           // [8] diagnostics: 0 sync rounds, 1 lane-passes in sync, 2 fix rounds, 3 lane-passes in fix
     uint32_t n_images, n_hwg, n_iwg, n_dcblk;
 };
 

@@ -1,0 +1,156 @@
+// decoder_main.cpp -- `bin/decoder <jpeg>...`: the reference's CLI on the MI355X path.
+//
+// Same contract as the reference's main() (reference src/decoder_host.cpp:352-451):
+//   * positional JPEG paths; inputs are processed in ascending file-size order (:360);
+//   * "<stem>.bmp" is written next to every decodable input (:328-330);
+//   * parse errors go to stdout as "<file>: Error - ..." followed by "<file>: Error - Invalid JPEG";
+//   * Huffman errors are printed and the (partial) picture is still written (:181);
+//   * exit code 0, or 1 with "Error - Invalid arguments" when no file is given (:353-356);
+//   * a "Profiles:" block with the same rows (:379-394).
+// What differs by construction: "<n> dpus are allocated" becomes a line about the GPU, the
+// producer/consumer pair is a scan stage followed by batched GPU decodes, and the four DPU cycle
+// counters become per-kernel milliseconds measured with HIP events.
+//
+// Extensions (do not change the default behaviour): --device N, --batch M (images per GPU batch).
+#include <sys/stat.h>
+#include <time.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/pjd.h"
+#include "../../include/pjd_host.h"
+
+static double now_s()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static std::string bmp_name(const std::string &in)
+{
+    const size_t pos = in.find_last_of('.');
+    return pos == std::string::npos ? in + ".bmp" : in.substr(0, pos) + ".bmp";
+}
+
+int main(int argc, char **argv)
+{
+    int device = 0;
+    size_t batch_images = 1024;
+    std::vector<std::string> files;
+    for (int i = 1; i < argc; i++) {
+        if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch_images = (size_t)std::atoll(argv[++i]);
+        else files.push_back(argv[i]);
+    }
+    if (files.empty()) {
+        std::cout << "Error - Invalid arguments\n";
+        return 1;
+    }
+    // ascending file size, like sort_by_size (decoder_host.cpp:46-61)
+    std::vector<std::pair<long long, std::string>> sized;
+    for (const std::string &f : files) {
+        struct stat st;
+        sized.emplace_back(stat(f.c_str(), &st) == 0 ? (long long)st.st_size : 0LL, f);
+    }
+    std::stable_sort(sized.begin(), sized.end(), [](const std::pair<long long, std::string> &a, const std::pair<long long, std::string> &b) { return a.first < b.first; });
+
+    pjd_ctx *ctx = nullptr;
+    int rc = pjd_open(device, &ctx);
+    if (rc != PJD_OK) {
+        std::cout << "Error - no usable MI355X (gfx950) device (pjd_open returned " << rc << ")\n";
+        return 2;
+    }
+    std::cout << "1 MI355X device is allocated\n";
+
+    double t_total = now_s(), t_scan = 0, t_upload = 0, t_exec = 0, t_download = 0, t_bmp = 0;
+    pjd_timings last_timings;
+    std::memset(&last_timings, 0, sizeof last_timings);
+    int calls = 0;
+
+    size_t next = 0;
+    while (next < sized.size()) {
+        // ---- scan stage (replaces mcu_prepare's read_JPEG loop, decoder_host.cpp:118-123)
+        double t0 = now_s();
+        std::vector<pjd_scanned *> scanned;
+        std::vector<std::string> names;
+        while (next < sized.size() && scanned.size() < batch_images) {
+            const std::string &f = sized[next++].second;
+            pjd_scanned *s = nullptr;
+            int sr = pjd_scan_file(f.c_str(), &s);
+            if (sr == 2) {
+                std::cout << f << ": Error - Error opening input file\n" << f << ": Error - Invalid JPEG\n";
+                continue;
+            }
+            std::cout << pjd_scanned_log(s);
+            if (sr != 0) { pjd_scanned_free(s); continue; }
+            scanned.push_back(s);
+            names.push_back(f);
+        }
+        t_scan += now_s() - t0;
+        if (scanned.empty()) continue;
+
+        std::vector<pjd_image_desc> descs;
+        for (pjd_scanned *s : scanned) descs.push_back(*pjd_scanned_desc(s));
+        pjd_batch *b = nullptr;
+        t0 = now_s();
+        rc = pjd_batch_create(ctx, descs.data(), (int)descs.size(), PJD_OUT_BMP, &b);
+        if (rc == PJD_OK) rc = pjd_batch_upload(b);
+        t_upload += now_s() - t0;
+        if (rc != PJD_OK) {
+            std::cout << "Error - GPU batch setup failed: " << pjd_last_error(ctx) << "\n";
+            for (pjd_scanned *s : scanned) pjd_scanned_free(s);
+            if (b) pjd_batch_destroy(b);
+            continue;
+        }
+        t0 = now_s();
+        rc = pjd_batch_decode_timed(b, &last_timings);
+        if (rc == PJD_OK) rc = pjd_batch_sync(b);
+        t_exec += now_s() - t0;
+        calls++;
+
+        std::vector<std::vector<uint8_t>> outs(descs.size());
+        std::vector<uint8_t *> ptrs(descs.size());
+        std::vector<int32_t> status(descs.size(), 0);
+        for (size_t i = 0; i < descs.size(); i++) {
+            outs[i].resize(pjd_batch_output_size(b, (int)i));
+            ptrs[i] = outs[i].data();
+        }
+        t0 = now_s();
+        if (rc == PJD_OK) rc = pjd_batch_download(b, ptrs.data(), status.data());
+        t_download += now_s() - t0;
+        if (rc != PJD_OK) std::cout << "Error - GPU decode failed: " << pjd_last_error(ctx) << "\n";
+
+        t0 = now_s();
+        for (size_t i = 0; i < descs.size() && rc == PJD_OK; i++) {
+            if (status[i] != PJD_ST_OK) std::cout << names[i] << ": " << pjd_status_string(status[i]) << "\n";
+            const std::string out = bmp_name(names[i]);
+            if (pjd_write_file(out.c_str(), outs[i].data(), outs[i].size()) != 0)
+                std::cout << out << ": Error - Unable to create BMP file" << std::endl;
+        }
+        t_bmp += now_s() - t0;
+        pjd_batch_destroy(b);
+        for (pjd_scanned *s : scanned) pjd_scanned_free(s);
+    }
+    t_total = now_s() - t_total;
+
+    std::cout << "\nProfiles:\n";
+    std::cout << "End-to-end execution time: " << t_total << "s\n";
+    std::cout << "MCU Offloader execution time (total): \n";
+    std::cout << " - JPEG scan time: " << t_scan << "s\n";
+    std::cout << " - CPU-to-GPU transfer time: " << t_upload << "s\n";
+    std::cout << " - GPU execution time: " << t_exec << "s\n";
+    for (int k = 0; k < last_timings.n; k++)
+        std::cout << " - GPU execution - " << last_timings.name[k] << ": " << last_timings.ms[k] << " ms (last batch)\n";
+    std::cout << " - GPU-to-CPU transfer time: " << t_download << "s\n";
+    std::cout << " - BMP write time: " << t_bmp << "s\n";
+    std::cout << " - Total " << calls << " calls\n";
+    pjd_close(ctx);
+    return 0;
+}

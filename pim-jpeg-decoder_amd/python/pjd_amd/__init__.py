@@ -52,7 +52,9 @@ class BatchInfo(C.Structure):
     _fields_ = [("n_images", C.c_int32), ("pixels", C.c_uint64), ("ecs_bytes", C.c_uint64),
                 ("out_bytes", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_data_units", C.c_uint64),
                 ("n_subsequences", C.c_uint64), ("device_bytes", C.c_uint64),
-                ("n_sequential", C.c_int32), ("n_fallback", C.c_int32)]
+                ("n_sequential", C.c_int32), ("n_fallback", C.c_int32),
+                ("n_huff_workgroups", C.c_uint64), ("sync_rounds", C.c_uint64), ("sync_lane_passes", C.c_uint64),
+                ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64)]
 
 
 class PjdError(RuntimeError):

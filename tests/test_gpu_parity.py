@@ -35,7 +35,7 @@ def _desc(name, flags=0):
 
 
 # ---- the literal DPU contract -------------------------------------------------------------
-@pytest.mark.parametrize("name", ["ilsvrc_val_00000001", "env_61x45_420_q85_opt", "env_72x40_422_q100", "h1v2_45x61",
+@pytest.mark.parametrize("name", ["ilsvrc_val_00000001", "env_61x45_420_q100_opt", "env_72x40_422_q30_opt", "h1v2_45x61",
                                   "gray_61x45", "noise_96x80_444_q100", "dqt16_64x48_444", "err_truncated_eoi_420"])
 def test_dpu_payload_matches_oracle(ctx, port, name):
     if name not in MANIFEST:
@@ -139,3 +139,82 @@ def test_empty_batch_and_bad_descriptor(ctx):
     s.desc.num_components = 4
     with pytest.raises(pjd_amd.PjdError):
         ctx.decode([s.desc])
+
+
+def test_cli_writes_reference_bmps(tmp_path):
+    """bin/decoder: same outputs and stdout shape as the reference's CLI (config #1 and friends)."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    names = ["ilsvrc_val_00000001", "env_61x45_420_q100_opt", "neg_progressive_64x48", "err_truncated_eoi_444", "div_rst_420_64x48"]
+    names = [n for n in names if n in MANIFEST]
+    for n in names:
+        shutil.copy(os.path.join(HERE, "golden", n + ".jpg"), tmp_path / (n + ".jpg"))
+    p = subprocess.run([os.path.join(ROOT, "bin", "decoder")] + [str(tmp_path / (n + ".jpg")) for n in names],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Profiles:" in p.stdout and "End-to-end execution time:" in p.stdout
+    for n in names:
+        ent = MANIFEST[n]
+        bmp = tmp_path / (n + ".bmp")
+        path = str(tmp_path / (n + ".jpg"))
+        for line in ent["stdout"].replace("{path}", path).splitlines():
+            assert line in p.stdout, line
+        if ent["rc"] != 0:
+            assert not bmp.exists()
+        else:
+            assert hashlib.sha256(bmp.read_bytes()).hexdigest() == ent["bmp_sha256"], n
+    q = subprocess.run([os.path.join(ROOT, "bin", "decoder")], capture_output=True, text=True)
+    assert q.returncode == 1 and q.stdout == "Error - Invalid arguments\n"
+
+
+def test_routing_parallel_path_is_the_one_that_runs(ctx):
+    """Regular streams must be decoded by the parallel kernels (no silent exact-kernel fallback);
+    broken streams and the no-EOB q100 noise streams must be re-decoded by the exact kernel."""
+    import pjd_amd
+    expect_fallback = {"err_corrupt_3", "err_truncated_eoi_420", "err_truncated_eoi_444"}
+    may_fallback = {"env_128x96_420_q100_opt", "env_200x150_420_q100_opt", "noise_96x80_444_q100", "env_61x45_420_q100_opt",
+                    "env_64x48_420_q100", "env_72x40_420_q100", "noise_96x80_420_q95", "noise_80x96_422_q50_opt"}
+    for name in VALID:
+        s = _desc(name)
+        with ctx.batch([s.desc]) as b:
+            b.upload()
+            b.decode()
+            b.download()
+            i = b.info()
+        if name.startswith("div_rst"):
+            assert i["n_sequential"] == 1, name          # reference restart rule with subsampled luma
+            continue
+        assert i["n_sequential"] == 0, name
+        if name in expect_fallback:
+            assert i["n_fallback"] == 1, name
+        elif name not in may_fallback:
+            assert i["n_fallback"] == 0, name
+
+
+@pytest.mark.parametrize("name,world", [("rstrow_200x150_444_opt", 2), ("rst4_128x96_444", 4), ("rstrow_gray_100x60", 3)])
+def test_sharded_single_image_union_matches_oracle(ctx, port, name, world):
+    """Config-5 mechanics on one GPU: decode each rank's restart-segment range as its own batch from
+    only that rank's slice of the bitstream; the union of the written MCU rows equals the oracle."""
+    import pjd_amd
+    from pjd_amd import parallel
+    s = _desc(name)
+    segs, ecs = s.seg_offsets(), s.ecs()
+    want = port.decode(golden_bytes(name))["rgb"]
+    got = np.zeros_like(want)
+    H = want.shape[0]
+    d0 = s.desc
+    mcux = (d0.width + 7) // 8
+    for r in range(world):
+        f, c = parallel.segment_range(len(segs), r, world)
+        lo = int(segs[f])
+        hi = int(segs[f + c]) if f + c < len(segs) else len(ecs)
+        d, keep = parallel.shard_descriptor(d0, segs, ecs[lo:hi], lo, r, world)
+        outs, st = ctx.decode([d], pjd_amd.OUT_RGB8)
+        assert st == [0]
+        m0, m1 = f * d0.restart_interval, min((f + c) * d0.restart_interval, mcux * ((d0.height + 7) // 8))
+        # copy the pixels of MCUs [m0, m1)
+        for m in range(m0, m1):
+            y0, x0 = (m // mcux) * 8, (m % mcux) * 8
+            got[y0:y0 + 8, x0:x0 + 8] = outs[0][y0:y0 + 8, x0:x0 + 8]
+    assert np.array_equal(got, want)

@@ -1,0 +1,84 @@
+"""N > 1 host logic on CPU: world_size-2 gloo processes exercise the sharding helpers
+(image LPT split, descriptor broadcast, ECS scatter, per-rank shard descriptors and their plans).
+No GPU compute here; the GPU side of sharding is covered by test_gpu_parity.py::test_sharded_*."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import golden_bytes, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, "pim-jpeg-decoder_amd", "python"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import pjd_amd
+    from pjd_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = golden_bytes("rstrow_200x150_444_opt")
+        if rank == 0:
+            s = pjd_amd.Scanned(data)
+            blob = parallel.pack_descriptor(s.desc, s.seg_offsets())
+            ecs, n = s.ecs(), int(s.desc.ecs_len)
+            segs0 = s.seg_offsets()
+        else:
+            blob, ecs, n, segs0 = None, None, 0, None
+        blob = parallel.broadcast_descriptor(blob, src=0)
+        desc, segs = parallel.unpack_descriptor(blob)
+        sl, lo = parallel.scatter_ecs(ecs, segs, desc.ecs_len if rank else n, src=0)
+        d, keep = parallel.shard_descriptor(desc, segs, sl, lo, rank, world)
+        info = pjd_amd.plan_info([d])
+        ret[rank] = {"w": int(desc.width), "h": int(desc.height), "nseg": int(desc.n_segments), "first": int(d.shard_first_seg),
+                     "count": int(d.shard_n_segs), "slice": len(sl), "lo": int(lo), "subs": info["n_subsequences"],
+                     "seq": info["n_sequential"], "sha": __import__("hashlib").sha256(sl.tobytes()).hexdigest()}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_descriptor_broadcast_and_scatter():
+    import hashlib
+    import pjd_amd
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    s = pjd_amd.Scanned(golden_bytes("rstrow_200x150_444_opt"))
+    segs, ecs = s.seg_offsets(), s.ecs()
+    assert ret[0]["nseg"] == ret[1]["nseg"] == len(segs) == 19
+    assert (ret[0]["w"], ret[0]["h"]) == (ret[1]["w"], ret[1]["h"]) == (200, 150)
+    assert ret[0]["first"] == 0 and ret[0]["count"] == 10 and ret[1]["first"] == 10 and ret[1]["count"] == 9
+    cut = int(segs[10])
+    assert ret[0]["slice"] == cut and ret[1]["slice"] == len(ecs) - cut and ret[1]["lo"] == cut
+    assert ret[0]["sha"] == hashlib.sha256(ecs[:cut].tobytes()).hexdigest()
+    assert ret[1]["sha"] == hashlib.sha256(ecs[cut:].tobytes()).hexdigest()
+    assert ret[0]["seq"] == 0 and ret[1]["seq"] == 0 and ret[0]["subs"] > 0 and ret[1]["subs"] > 0
+
+
+def test_lpt_and_segment_ranges():
+    from pjd_amd import parallel
+    costs = [9, 1, 8, 2, 7, 3, 6, 4, 5]
+    parts = parallel.lpt_assign(costs, 3)
+    assert sorted(sum(parts, [])) == list(range(9))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= 2
+    for n in (1, 7, 8, 19, 2048):
+        for w in (1, 2, 4, 8):
+            got = [parallel.segment_range(n, r, w) for r in range(w)]
+            assert sum(c for _, c in got) == n
+            assert all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(w - 1))

@@ -76,7 +76,7 @@ def test_port_matches_ref_fields(port, ref, tmp_path, name):
 
 def test_stage_entry_points_compose(port):
     """dequant -> idct -> colour one by one == orc_dpu_exec."""
-    out = port.decode(golden_bytes("env_61x45_420_q85_opt") if "env_61x45_420_q85_opt" in NAMES else golden_bytes(NAMES[0]))
+    out = port.decode(golden_bytes("env_61x45_420_q100_opt"))
     meta = out["metadata"]
     a = out["coef"][0].copy()
     b = out["coef"][0].copy()
