@@ -26,6 +26,7 @@ struct pjd_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool force_sequential = false;
+    uint32_t sub_bytes_override = 0;
 };
 
 #define HIP_TRY(ctx, call)                                                                      \
@@ -110,6 +111,8 @@ int pjd_open(int device_ordinal, pjd_ctx **out)
     }
     const char *fs = std::getenv("PJD_FORCE_SEQUENTIAL");
     c->force_sequential = fs && fs[0] == '1';
+    const char *sb = std::getenv("PJD_SUB_BYTES");
+    c->sub_bytes_override = sb ? (uint32_t)std::atoi(sb) : 0;
     *out = c;
     return PJD_OK;
 }
@@ -150,7 +153,7 @@ void pjd_batch_destroy(pjd_batch *b)
     if (b->graph) hipGraphDestroy(b->graph);
     void *ptrs[] = { b->d_images, b->d_raw, b->d_qtab, b->d_segs, b->d_subs, b->d_hwgs, b->d_iwgs, b->d_ecs,
                      b->d_dcblk_image, b->d_seq_list, b->d_fb_list, b->d_fb_iwgs, b->d_status_init,
-                     b->dev.luts, b->dev.coef, b->dev.out, b->dev.status, b->dev.sub_exit, b->dev.sub_cnt,
+                     b->dev.luts, b->dev.coef, b->dev.out, b->dev.status, b->dev.sub_exit, b->dev.sub_cnt, b->dev.sub_chk,
                      b->dev.wg_entry, b->dev.wg_exit, b->dev.wg_agg, b->dev.wg_du_in, b->dev.dc_agg, b->dev.dc_carry, b->dev.stats };
     for (void *p : ptrs) if (p) hipFree(p);
     if (b->h_ecs) hipHostFree(b->h_ecs);
@@ -164,7 +167,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     *out = nullptr;
     pjd_batch *b = new pjd_batch;
     b->ctx = ctx;
-    int rc = pjd_make_plan(images, n_images, out_format, b->plan, ctx->err);
+    int rc = pjd_make_plan(images, n_images, out_format, b->plan, ctx->err, ctx->sub_bytes_override);
     if (rc != PJD_OK) { delete b; return rc; }
     PjdPlan &P = b->plan;
     hipSetDevice(ctx->device);
@@ -207,6 +210,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->dev.sub_exit, P.subs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.sub_cnt, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.sub_chk, P.subs.size() * 2 * PJD_NCHK, tot));
     TRY_RC(dev_alloc(ctx, b->dev.wg_entry, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.wg_exit, P.hwgs.size() * 2, tot));
     TRY_RC(dev_alloc(ctx, b->dev.wg_agg, P.hwgs.size() * 2, tot));
@@ -220,6 +224,9 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     b->dev.ecs = b->d_ecs; b->dev.dcblk_image = b->d_dcblk_image;
     b->dev.n_images = (uint32_t)n_images; b->dev.n_hwg = (uint32_t)P.hwgs.size();
     b->dev.n_iwg = (uint32_t)P.iwgs.size(); b->dev.n_dcblk = (uint32_t)P.n_dcblk;
+    b->dev.sub_bytes = P.sub_bytes;
+    b->dev.max_tables = 1;
+    for (const PjdDevImage &im : P.images) if (im.n_tables > b->dev.max_tables) b->dev.max_tables = im.n_tables;
     *out = b;
     return PJD_OK;
 }

@@ -7,12 +7,14 @@
 #include <stdint.h>
 
 // ---- tunables -----------------------------------------------------------------
-#define PJD_SUBSEQ_BYTES   128      // bitstream bytes per Huffman decode lane
-#define PJD_HUFF_THREADS   256      // lanes per Huffman workgroup
-#define PJD_HUFF_OWNED     255      // subsequences owned per workgroup (lane 0 = predecessor overlap)
+#define PJD_SUB_BYTES_MIN  128      // Huffman subsequence (bytes of bitstream per decode lane): chosen per batch
+#define PJD_SUB_BYTES_MAX  1024     //   by the planner (power of two in this range), see pjd_plan.cpp
+#define PJD_HUFF_THREADS   64       // one wave per Huffman workgroup: lanes exchange states by shuffles, no barriers
+#define PJD_HUFF_OWNED     63       // subsequences owned per workgroup (lane 0 = predecessor overlap)
+#define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into)
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_MAX_TABLES     6        // distinct Huffman tables one image can reference (3 DC + 3 AC)
-#define PJD_SYNC_MAX_ITERS 24       // intra-workgroup re-sync rounds before giving up (-> exact fallback)
+#define PJD_SYNC_MAX_ITERS 24       // re-sync rounds per wave before giving up (-> exact fallback)
 #define PJD_DC_BLOCK       256      // MCUs per DC-prediction scan block
 #define PJD_IDCT_THREADS   256
 #define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup
@@ -61,11 +63,13 @@ struct PjdDevHuffRaw {
 // decode-ready table, built on the device by pjd_k_build_tables
 struct PjdDevHuffLut {
     uint16_t lut[1 << PJD_LUT_BITS];   // (code length << 8) | symbol ; 0 => longer than LUT_BITS or invalid
-    uint32_t first[17];                // first[L] = code value of the first code of length L (reference generate_codes)
-    uint8_t  offs[20];                 // offsets[0..16]
+    uint32_t lim[8];                   // lim[k] = left-aligned 16-bit upper bound of codes of length <= LUT_BITS+k (k=0..6), lim[7] pad
+    int32_t  base[17];                 // base[L] = offsets[L-1] - first_code[L]  (symbol index = base[L] + code)
     uint8_t  symbols[164];
-};                                     // 2048 + 68 + 20 + 164 = 2300 bytes
-#define PJD_LUT_STRUCT_BYTES 2300
+    uint32_t irregular;                // 1 if the table is not a proper prefix code (over-subscribed): exact kernel only
+    uint32_t pad_;
+};                                     // 2048 + 32 + 68 + 164 + 8 = 2320 bytes
+#define PJD_LUT_STRUCT_BYTES 2320
 
 struct PjdDevSegment {                 // one restart segment
     uint32_t byte_start;               // relative to the image's ecs

@@ -1,42 +1,53 @@
-// pjd_k_huffman.hip -- the PARALLEL entropy decoder for gfx950.
+// pjd_k_huffman.hip -- the PARALLEL entropy decoder for gfx950 (v2).
 //
 // Huffman decoding is one dependent chain per restart segment; a batch of ImageNet files has
-// ~10^3 chains, a single 4K picture has one.  To fill 256 CUs the bitstream is cut into
-// fixed 128-byte SUBSEQUENCES, one decode lane each, and the lanes find their true entry
-// states by self-synchronisation (a decoder started at a wrong position falls into step with
-// the true one after a few symbols; Weissenberger & Schmidt describe the scheme for GPUs):
+// ~10^3 chains, a single 4K picture has one.  To fill 256 CUs the bitstream is cut into fixed
+// SUBSEQUENCES (128..1024 bytes, chosen per batch), one decode lane each, and lanes find their true
+// entry states by self-synchronisation: a decoder started at a wrong position falls into step
+// with the true one after a while (the scheme Weissenberger & Schmidt describe for GPUs).
+// Measured on 4:2:0 streams the distance to synchronisation is ~160 B on average with 5 % above
+// 512 B -- bit position, zigzag slot AND the 6-unit MCU phase must all agree -- which shapes
+// everything below:
 //
-//   pjd_k_build_tables   raw (offsets, symbols) tables -> 10-bit first-level LUT + canonical
-//                        arrays; semantics of reference generate_codes / get_next_symbol
-//                        (reference src/jpeg_scanner.cpp:438-465)
-//   pjd_k_huff_sync      one workgroup = 255 owned subsequences of one image (+1 overlap lane).
-//                        Bitstream bytes are staged ONCE into LDS with coalesced 16-byte loads,
-//                        byte-swapped, 33-dword padded rows (bank-conflict free); tables in LDS.
-//                        Every lane decodes its subsequence speculatively, then lanes re-decode
-//                        from their predecessor's exit state until nothing changes.
-//   pjd_k_huff_fix       stitches workgroup boundaries (the overlap lane's guess vs the truth)
-//                        and reduces per-workgroup data-unit counts
+//   * lanes read their own subsequence straight from HBM, 16 bytes at a time with the next chunk
+//     always in flight; nothing is staged in LDS, so occupancy is not LDS-bound and a workgroup is
+//     ONE wave (63 owned subsequences + 1 overlap lane): states travel by wave shuffles, there are
+//     no barriers;
+//   * round 0 decodes every subsequence speculatively and leaves PJD_NCHK checkpoints of the
+//     trajectory (state + data units still to come) in LDS;
+//   * in a re-sync round a lane restarts from its predecessor's exit state and stops as soon as
+//     its state equals a checkpoint ("bridge"): the usual cost is the synchronisation distance,
+//     not a whole subsequence.  Only a lane that crosses its whole subsequence unmerged hands a
+//     changed exit state on to its successor for the next round.
+//
+//   pjd_k_build_tables   raw (offsets, symbols) tables -> 10-bit first-level LUT + length limits
+//                        (semantics of reference generate_codes / get_next_symbol,
+//                        reference src/jpeg_scanner.cpp:438-465)
+//   pjd_k_huff_sync      rounds as above; exit state and data-unit count per subsequence
+//   pjd_k_huff_fix       stitches wave boundaries (overlap lane's guess vs the predecessor wave's
+//                        truth; a mismatching wave is redone) and reduces per-wave unit counts
 //   pjd_k_huff_carry     one wave per image: scan of those counts -> absolute data-unit index
-//   pjd_k_huff_write     final pass from the now-known entry states: coefficients are written,
-//                        in zigzag-slot order, to coef[(du_base + D) * 64 + slot]; slot 0 holds
-//                        the DC DIFFERENCE (pjd_k_dc_* integrates it)
+//   pjd_k_huff_write     final pass from the now-known entry states: coefficients are written, in
+//                        zigzag-slot order, to coef[(du_base + D) * 64 + slot]; slot 0 holds the
+//                        DC DIFFERENCE (pjd_k_dc_* integrates it)
 //
 // Exactness: a lane that starts from the true state performs exactly the reference's
-// decode_MCU_component (reference src/jpeg_scanner.cpp:467-520).  Anything irregular seen in
-// the final pass -- an invalid code, a size or run outside the baseline limits, a segment that
-// ends early or late, a boundary that did not stitch -- sets PJD_STW_NEEDS_EXACT on the image
-// and the host re-decodes it with the one-lane exact kernel (pjd_k_huffman_seq.hip).
+// decode_MCU_component (reference src/jpeg_scanner.cpp:467-520).  Anything irregular seen in the
+// final pass -- invalid code, size or run outside the baseline limits, a segment that ends early or
+// late, a boundary that did not stitch, a lane that does not reproduce its synchronised exit --
+// sets PJD_STW_NEEDS_EXACT and the host re-decodes that image with the one-lane exact kernel.
 #include "pjd_device_common.h"
 #include "pjd_kernels.h"
 
-#define LUT_BYTES        PJD_LUT_STRUCT_BYTES
-#define STREAM_DWORDS    8512                 // (256*128 + 15 + 16 + 15)/4 rounded up, plus 1/32 padding
-#define OFF_FIRST        (2 << PJD_LUT_BITS)  // byte offsets inside PjdDevHuffLut
-#define OFF_OFFS         (OFF_FIRST + 68)
-#define OFF_SYMS         (OFF_OFFS + 20)
+#define LUT_BYTES   PJD_LUT_STRUCT_BYTES
+#define OFF_LIM     (2 << PJD_LUT_BITS)          // byte offsets inside PjdDevHuffLut
+#define OFF_BASE    (OFF_LIM + 32)
+#define OFF_SYMS    (OFF_BASE + 68)
+#define OFF_IRR     (OFF_SYMS + 164)
 
 static_assert(sizeof(PjdDevHuffLut) == LUT_BYTES, "LUT struct layout");
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
+static_assert(PJD_LUT_BITS == 10, "lim[] covers lengths 10..16");
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
@@ -47,14 +58,18 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
     PjdDevHuffLut &o = B.luts[(size_t)img * PJD_MAX_TABLES + slot];
     __shared__ uint32_t first[17];
     __shared__ uint8_t offs[17];
+    __shared__ uint32_t irregular;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
-        uint32_t code = 0;                       // reference generate_codes
+        uint32_t code = 0, irr = 0;              // reference generate_codes
         first[0] = 0;
         for (int len = 1; len <= 16; len++) {
             first[len] = code;
-            code = (code + (uint32_t)(r.offsets[len] - r.offsets[len - 1])) << 1;
+            const uint32_t cnt = (uint32_t)(r.offsets[len] - r.offsets[len - 1]);
+            if (code + cnt > (1u << len)) irr = 1;        // over-subscribed: not a prefix code
+            code = (code + cnt) << 1;
         }
+        irregular = irr;
     }
     if (tid < 17) offs[tid] = r.offsets[tid];
     __syncthreads();
@@ -67,233 +82,280 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
         }
         o.lut[idx] = e;
     }
-    if (tid < 17) { o.first[tid] = first[tid]; o.offs[tid] = offs[tid]; }
+    // lim[k]: a 16-bit window w holds a code of length <= 10+k  <=>  w < lim[k]
+    if (tid < 8) {
+        const uint32_t len = PJD_LUT_BITS + tid;
+        uint32_t v = 0;
+        if (len <= 16) {
+            const uint32_t cnt = (uint32_t)offs[len] - offs[len - 1];
+            v = (first[len] + cnt) << (16 - len);
+            if (v > 65536u) v = 65536u;
+        }
+        o.lim[tid] = v;
+    }
+    if (tid >= 1 && tid < 17) o.base[tid] = (int32_t)offs[tid - 1] - (int32_t)first[tid];
+    if (tid == 0) { o.base[0] = 0; o.irregular = irregular; o.pad_ = 0; }
     if (tid < 164) o.symbols[tid] = tid < 162 ? r.symbols[tid] : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-lane decoder over the LDS-staged stream.
+// Bit window over the lane's own stream, fed from HBM 16 bytes at a time, one chunk ahead.
 // ---------------------------------------------------------------------------------------------
-struct HuffLds {
-    uint32_t stream[STREAM_DWORDS];                                  // big-endian dwords, row-padded
-    __attribute__((aligned(4))) uint8_t tabs[PJD_MAX_TABLES * LUT_BYTES];
-};
-
-// table slot (0..5) of {DC,AC} x component, 4 bits each: bits [4*(2*comp+is_ac) +: 4].  One register,
-// selected arithmetically -- a struct of six offsets gets demoted to scratch memory by the compiler.
-struct LaneTables { uint32_t packed; };
-
-__device__ __forceinline__ uint32_t stream_dword(const uint32_t *s, uint32_t d) { return s[d + (d >> 5)]; }
-
 struct BitWin {
+    const uint4 *ptr;     // next chunk to fetch
+    uint4 cur, nxt;
+    uint32_t k;           // dwords left in cur
     uint64_t buf;
     int cnt;
-    uint32_t nd;
-    __device__ __forceinline__ void init(const uint32_t *s, uint32_t p)
+    __device__ __forceinline__ uint32_t take()
     {
-        nd = p >> 5;
-        buf = ((uint64_t)stream_dword(s, nd) << 32) | stream_dword(s, nd + 1);
-        nd += 2;
+        if (k == 0) {
+            cur = nxt;
+            // keep the copy above ahead of the load below: the load can then target nxt's registers
+            // directly and is first waited for a whole chunk (~20 symbols) later
+            asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w));
+            nxt = *ptr++;
+            k = 4;
+        }
+        const uint32_t w = __builtin_bswap32(cur.x);
+        cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+        k--;
+        return w;
+    }
+    // `base16`: 16-byte aligned stream origin; p: bit offset from it
+    __device__ __forceinline__ void init(const uint4 *base16, uint32_t p)
+    {
+        ptr = base16 + (p >> 7);
+        cur = ptr[0]; nxt = ptr[1]; ptr += 2;
+        k = 4;
+        const uint32_t skip = (p >> 5) & 3;
+        if (skip >= 1) { cur.x = cur.y; cur.y = cur.z; cur.z = cur.w; k--; }
+        if (skip >= 2) { cur.x = cur.y; cur.y = cur.z; k--; }
+        if (skip >= 3) { cur.x = cur.y; k--; }
+        const uint32_t hi = take(), lo = take();
+        buf = ((uint64_t)hi << 32) | lo;
         cnt = 64 - (int)(p & 31);
         buf <<= (p & 31);
     }
-    __device__ __forceinline__ uint32_t peek(const uint32_t *s)
+    __device__ __forceinline__ uint32_t peek()
     {
-        if (cnt <= 32) { buf |= (uint64_t)stream_dword(s, nd++) << (32 - cnt); cnt += 32; }
+        if (cnt <= 32) { buf |= (uint64_t)take() << (32 - cnt); cnt += 32; }
         return (uint32_t)(buf >> 32);
     }
     __device__ __forceinline__ void drop(uint32_t n) { buf <<= n; cnt -= (int)n; }
 };
 
-// Decodes symbols that START before end_bit.  State (p, c, z): bit position relative to the
-// staged base, data-unit phase within the MCU, zigzag slot (0 = DC expected).
-template <bool WRITE>
-__device__ __forceinline__ void decode_span(const HuffLds &L, const LaneTables &T, uint32_t nl, uint32_t dus,
-                                            uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
-                                            uint32_t &ndu, uint32_t &err,
+enum { MODE_SPEC = 0, MODE_BRIDGE = 1, MODE_WRITE = 2 };
+
+struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided by lane)
+    uint32_t *state;       // [PJD_NCHK][64] at this lane's column
+    uint32_t *rem;         // [PJD_NCHK][64]
+    uint32_t start_bit;    // first bit of the subsequence (relative to the lane's base16)
+    uint32_t chk_bits;     // checkpoint spacing
+};
+
+// Decodes symbols that START before end_bit.  State (p, c, z): bit position relative to base16,
+// data-unit phase within the MCU, zigzag slot (0 = DC expected).  Returns true when a BRIDGE pass
+// merged into the recorded trajectory (then ndu already includes the units still to come).
+template <int MODE>
+__device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacked, uint32_t nl, uint32_t dus,
+                                            const uint4 *base16, uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
+                                            uint32_t &ndu, uint32_t &err, const ChkCtx &K,
                                             int16_t *coef_img, uint32_t &D, uint32_t D_end)
 {
-    if (p >= end_bit) return;
+    if (p >= end_bit) return false;
     BitWin w;
-    w.init(L.stream, p);
-    while (p < end_bit && (!WRITE || D < D_end)) {
-        const uint32_t pk = w.peek(L.stream);
+    w.init(base16, p);
+    uint32_t j = 1, next_chk = K.start_bit + K.chk_bits;
+    bool merged = false;
+    while (p < end_bit && (MODE != MODE_WRITE || D < D_end)) {
+        if (MODE != MODE_WRITE && p >= next_chk) {
+            const uint32_t st = ((p - K.start_bit) << 12) | (c << 8) | z;      // p-start < 2^14, c < 16, z < 64
+            if (MODE == MODE_BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; merged = true; break; }
+            K.state[j * 64] = st;
+            K.rem[j * 64] = ndu;                                                // turned into "still to come" after the pass
+            j++;
+            next_chk += K.chk_bits;
+        }
+        const uint32_t pk = w.peek();
         const bool is_dc = (z == 0);
         const uint32_t comp = (c >= nl ? 1u : 0u) + (c > nl ? 1u : 0u);
-        const uint32_t tb = ((T.packed >> (8 * comp + (is_dc ? 0u : 4u))) & 15u) * LUT_BYTES;
-        const uint8_t *tab = L.tabs + tb;
+        const uint8_t *tab = tabs + ((tpacked >> (8 * comp + (is_dc ? 0u : 4u))) & 15u) * LUT_BYTES;
         const uint32_t e = *reinterpret_cast<const uint16_t *>(tab + 2 * (pk >> (32 - PJD_LUT_BITS)));
         uint32_t len = e >> 8, sym = e & 255;
-        if (len == 0) {                                   // code longer than the LUT (rare) or invalid
-            const uint32_t *first = reinterpret_cast<const uint32_t *>(tab + OFF_FIRST);
-            const uint8_t *offs = tab + OFF_OFFS;
-            const uint32_t code16 = pk >> 16;
-            len = 16; sym = 0;
-            bool found = false;
-            for (uint32_t l = PJD_LUT_BITS + 1; l <= 16; l++) {
-                const uint32_t cc = code16 >> (16 - l);
-                const uint32_t d = cc - first[l], n = (uint32_t)offs[l] - offs[l - 1];
-                if (cc >= first[l] && d < n) { sym = tab[OFF_SYMS + offs[l - 1] + d]; len = l; found = true; break; }
-            }
-            if (!found) err |= 1;
+        if (__builtin_expect(len == 0, 0)) {
+            // code longer than the LUT (rare) or invalid: its length follows from comparing the 16-bit
+            // window with the per-length limits of the canonical code; the symbol index bases for all
+            // candidate lengths are fetched together with the limits, so only ONE dependent read remains
+            const uint32_t w16 = pk >> 16;
+            const uint4 la = *reinterpret_cast<const uint4 *>(tab + OFF_LIM);          // limits, lengths 10..13
+            const uint4 lb = *reinterpret_cast<const uint4 *>(tab + OFF_LIM + 16);     // limits, lengths 14..16
+            const int32_t *bp = reinterpret_cast<const int32_t *>(tab + OFF_BASE);
+            const int32_t b11 = bp[11], b12 = bp[12], b13 = bp[13], b14 = bp[14], b15 = bp[15], b16 = bp[16];
+            len = PJD_LUT_BITS + 1 + (w16 >= la.y) + (w16 >= la.z) + (w16 >= la.w) + (w16 >= lb.x) + (w16 >= lb.y);
+            const int32_t bs = len == 11 ? b11 : len == 12 ? b12 : len == 13 ? b13 : len == 14 ? b14 : len == 15 ? b15 : b16;
+            const bool bad = w16 >= lb.z;
+            const uint32_t idx = bad ? 0u : (uint32_t)(bs + (int32_t)(w16 >> (16 - len)));
+            sym = bad ? 0u : tab[OFF_SYMS + (idx < 162u ? idx : 0u)];
+            len = bad ? 16u : len;
+            err |= bad;
         }
         const uint32_t size = sym & 15, run = sym >> 4;
-        const uint32_t bits = size ? ((pk << len) >> (32 - size)) : 0;
-        int val = (int)bits;
-        if (size && !(bits >> (size - 1))) val -= (int)((1u << size) - 1);
         const uint32_t used = len + size;
         w.drop(used);
         p += used;
-        if (is_dc) {
-            err |= (sym > 11);                            // jpeg_scanner.cpp:470-477
-            if (WRITE) coef_img[(size_t)D * 64] = (int16_t)val;
-            z = 1;
-        } else if (sym == 0) {
-            z = 64;                                       // EOB
-        } else {
-            z += run;
-            if (z > 63) { err |= 1; z = 64; }             // jpeg_scanner.cpp:500
-            else {
-                err |= (size > 10);                       // jpeg_scanner.cpp:506
-                if (WRITE) {
-                    if (size) coef_img[(size_t)D * 64 + z] = (int16_t)val;
-                    else if (z == 52) coef_img[(size_t)D * 64 + z] = (int16_t)PJD_COEF_SENTINEL;
-                }
-                z += 1;
-            }
+        // state update without branches (reference src/jpeg_scanner.cpp:469-518)
+        const uint32_t zr = z + run;                       // landing slot of an AC symbol
+        const bool eob = (sym == 0), over = zr > 63;
+        const uint32_t z_ac = (eob || over) ? 64u : zr + 1;
+        const uint32_t znew = is_dc ? 1u : z_ac;
+        err |= is_dc ? (sym > 11) : (!eob && (over || size > 10));
+        if (MODE == MODE_WRITE) {
+            const uint32_t bits = size ? ((pk << len) >> (32 - size)) : 0;
+            int val = (int)bits;
+            if (size && !(bits >> (size - 1))) val -= (int)((1u << size) - 1);
+            const uint32_t slot = is_dc ? 0u : zr;
+            const bool store = is_dc || (!eob && !over && (size != 0 || zr == 52));
+            if (store) coef_img[(size_t)D * 64 + slot] = (size == 0 && !is_dc) ? (int16_t)PJD_COEF_SENTINEL : (int16_t)val;
         }
-        if (z >= 64) {
-            z = 0;
-            c = (c + 1 == dus) ? 0 : c + 1;
-            ndu++;
-            if (WRITE) D++;
-        }
+        const bool done = znew >= 64;
+        z = done ? 0u : znew;
+        c = done ? ((c + 1 == dus) ? 0u : c + 1) : c;
+        ndu += done;
+        if (MODE == MODE_WRITE) D += done;
     }
+    if (MODE != MODE_WRITE) {
+        // checkpoints (re)written in this pass hold "units so far"; make them "units still to come"
+        for (uint32_t i = 1; i < j; i++) K.rem[i * 64] = ndu - K.rem[i * 64];
+    }
+    return merged;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Common per-workgroup set-up: lane geometry, LDS staging of bitstream and tables.
+// Per-wave set-up.
 // ---------------------------------------------------------------------------------------------
 struct LaneGeom {
     bool valid, owned, seg_first, seg_last;
-    uint32_t q;              // global subsequence index
-    uint32_t seg;            // global segment index
-    uint32_t start_bit, end_bit;   // relative to the staged base
-    uint32_t seg_end_bit;          // relative to the staged base (may be far beyond the staged window)
-    uint32_t base_bit;       // staged base, bits relative to the image's ecs
+    uint32_t q;                    // global subsequence index
+    uint32_t seg;                  // global segment index
+    uint32_t start_bit, end_bit;   // relative to base16
+    uint32_t seg_end_bit;
+    uint32_t base_bit;             // base16, in bits relative to the image's ecs
+    const uint4 *base16;           // the lane's own origin: its subsequence start rounded down to 16 bytes
 };
 
-__device__ __forceinline__ void wg_setup(const PjdDevBatch &B, const PjdDevHuffWg &wg, const PjdDevImage &im,
-                                         HuffLds &L, LaneGeom &g, LaneTables &T, bool stage)
+extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][chk_state 8x64 u32][chk_rem 8x64 u32]
+
+__device__ __forceinline__ void wave_setup(const PjdDevBatch &B, const PjdDevHuffWg &wg, const PjdDevImage &im,
+                                           LaneGeom &g, uint32_t &tpacked, ChkCtx &K)
 {
     const uint32_t t = threadIdx.x;
     const bool first_is_head = (B.subs[wg.first_sub].seg >> 31) != 0;
     g.owned = t >= 1 && t - 1 < wg.n_sub;
     g.valid = g.owned || (t == 0 && !first_is_head);
     g.q = wg.first_sub + t - 1;
-    const uint32_t lane_lo = first_is_head ? 1 : 0;
-    const uint32_t lo_byte = B.subs[wg.first_sub + lane_lo - 1].byte_start;
-    const uint32_t lo16 = lo_byte & ~15u;
-    g.base_bit = lo16 * 8;
     g.seg_first = g.seg_last = false;
-    g.seg = 0; g.start_bit = g.end_bit = g.seg_end_bit = 0;
+    g.seg = 0; g.start_bit = g.end_bit = g.seg_end_bit = g.base_bit = 0;
+    g.base16 = reinterpret_cast<const uint4 *>(B.ecs + im.ecs_off);
     if (g.valid) {
         const PjdDevSub sb = B.subs[g.q];
         g.seg = sb.seg & 0x7fffffffu;
         g.seg_first = (sb.seg >> 31) != 0;
         const PjdDevSegment sg = B.segs[g.seg];
-        const uint32_t end_byte = sb.byte_start + PJD_SUBSEQ_BYTES < sg.byte_end ? sb.byte_start + PJD_SUBSEQ_BYTES : sg.byte_end;
+        const uint32_t end_byte = sb.byte_start + B.sub_bytes < sg.byte_end ? sb.byte_start + B.sub_bytes : sg.byte_end;
         g.seg_last = end_byte == sg.byte_end;
+        const uint32_t lo16 = sb.byte_start & ~15u;
+        g.base_bit = lo16 * 8;
+        g.base16 = reinterpret_cast<const uint4 *>(B.ecs + im.ecs_off + lo16);
         g.start_bit = (sb.byte_start - lo16) * 8;
         g.end_bit = (end_byte - lo16) * 8;
         g.seg_end_bit = (sg.byte_end - lo16) * 8;
     }
-    T.packed = 0;
+    tpacked = 0;
     for (int cc = 0; cc < 3; cc++)
-        T.packed |= ((uint32_t)im.tbl_slot[cc][0] << (8 * cc)) | ((uint32_t)im.tbl_slot[cc][1] << (8 * cc + 4));
-    if (!stage) return;
-    // bitstream: [lo16, end of the last owned subsequence + 16), 16 B per lane per step
-    const PjdDevSub last = B.subs[wg.first_sub + wg.n_sub - 1];
-    const PjdDevSegment lseg = B.segs[last.seg & 0x7fffffffu];
-    const uint32_t hi_byte = (last.byte_start + PJD_SUBSEQ_BYTES < lseg.byte_end ? last.byte_start + PJD_SUBSEQ_BYTES : lseg.byte_end) + 16;
-    const uint32_t n16 = (hi_byte - lo16 + 15) / 16;
-    const uint4 *src = reinterpret_cast<const uint4 *>(B.ecs + im.ecs_off + lo16);
-    for (uint32_t i = t; i < n16; i += PJD_HUFF_THREADS) {
-        const uint4 v = src[i];
-        const uint32_t d = 4 * i, ph = d + (d >> 5);
-        L.stream[ph] = __builtin_bswap32(v.x);
-        L.stream[ph + 1] = __builtin_bswap32(v.y);
-        L.stream[ph + 2] = __builtin_bswap32(v.z);
-        L.stream[ph + 3] = __builtin_bswap32(v.w);
+        tpacked |= ((uint32_t)im.tbl_slot[cc][0] << (8 * cc)) | ((uint32_t)im.tbl_slot[cc][1] << (8 * cc + 4));
+    // tables -> LDS (16 B per lane per step)
+    const uint32_t n16 = im.n_tables * (LUT_BYTES / 16);
+    const uint4 *tsrc = reinterpret_cast<const uint4 *>(B.luts + (size_t)wg.image * PJD_MAX_TABLES);
+    uint4 *tdst = reinterpret_cast<uint4 *>(pjd_huff_lds);
+    for (uint32_t i0 = 0; i0 < n16; i0 += 4 * PJD_HUFF_THREADS) {      // 4 loads in flight per lane
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * PJD_HUFF_THREADS + t; if (i < n16) v[u] = tsrc[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * PJD_HUFF_THREADS + t; if (i < n16) tdst[i] = v[u]; }
     }
-    // zero the few dwords a refill may touch past the copied range
-    if (t < 8) { const uint32_t d = 4 * n16 + t; L.stream[d + (d >> 5)] = 0; }
-    // tables
-    const uint32_t *tsrc = reinterpret_cast<const uint32_t *>(B.luts + (size_t)wg.image * PJD_MAX_TABLES);
-    uint32_t *tdst = reinterpret_cast<uint32_t *>(L.tabs);
-    const uint32_t ndw = im.n_tables * (LUT_BYTES / 4);
-    for (uint32_t i = t; i < ndw; i += PJD_HUFF_THREADS) tdst[i] = tsrc[i];
-    __syncthreads();
+    uint32_t *chk = reinterpret_cast<uint32_t *>(pjd_huff_lds + B.max_tables * LUT_BYTES);
+    K.state = chk + t;
+    K.rem = chk + PJD_NCHK * 64 + t;
+    K.start_bit = g.start_bit;
+    K.chk_bits = B.sub_bytes * 8 / PJD_NCHK;
+    for (int j = 0; j < PJD_NCHK; j++) { K.state[j * 64] = 0xffffffffu; K.rem[j * 64] = 0; }
+    __syncthreads();          // one wave: a wait on the LDS stores
 }
 
-// Re-synchronisation rounds: lane t (owned, not at a segment start) re-decodes from E[t-1]
-// whenever E[t-1] changed in the previous round.  Returns false if the cap was hit.
-__device__ __forceinline__ bool resync_rounds(const HuffLds &L, const LaneTables &T, const LaneGeom &g,
-                                              uint32_t nl, uint32_t dus,
-                                              uint32_t *Ep, uint32_t *Ecz, uint32_t *Ecnt, uint32_t *chg /*[2][256]*/,
-                                              unsigned long long *stats, int stat_base)
+// Lanes have different origins, so states are exchanged as bit positions relative to the image's ecs.
+struct WaveState { uint32_t p_img, cz, cnt; };
+
+__device__ __forceinline__ bool wave_rounds(const PjdDevImage &im, const LaneGeom &g, uint32_t tpacked,
+                                            const ChkCtx &K, WaveState &S, uint32_t changed, unsigned long long *stats, int stat_base)
 {
-    const uint32_t t = threadIdx.x;
-    int cur = 0;
+    const uint8_t *tabs = pjd_huff_lds;
+    const uint32_t nl = im.n_luma, dus = im.dus_per_mcu;
     for (int iter = 0; iter < PJD_SYNC_MAX_ITERS; iter++) {
-        const bool act = g.owned && !g.seg_first && chg[cur * PJD_HUFF_THREADS + t - 1] != 0;
-        uint32_t p = 0, c = 0, z = 0;
-        if (act) { p = Ep[t - 1]; const uint32_t cz = Ecz[t - 1]; c = cz >> 8; z = cz & 255; }
-        __syncthreads();
-        if (act && stats) atomicAdd(stats + stat_base + 1, 1ull);
-        if (threadIdx.x == 0 && stats) atomicAdd(stats + stat_base, 1ull);
-        uint32_t changed = 0;
+        const uint32_t pp = __shfl_up(S.p_img, 1), pcz = __shfl_up(S.cz, 1), pch = __shfl_up(changed, 1);
+        const bool act = g.owned && !g.seg_first && pch != 0;
+        if (!__any(act)) return true;
+        if (stats && threadIdx.x == 0) atomicAdd(stats + stat_base, 1ull);
+        changed = 0;
         if (act) {
-            uint32_t ndu = 0, err = 0, D = 0;
-            decode_span<false>(L, T, nl, dus, p, c, z, g.end_bit, ndu, err, nullptr, D, 0);
-            const uint32_t cz = (c << 8) | z;
-            Ecnt[t] = ndu;
-            if (p != Ep[t] || cz != Ecz[t]) { Ep[t] = p; Ecz[t] = cz; changed = 1; }
+            if (stats) atomicAdd(stats + stat_base + 1, 1ull);
+            uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, err = 0, D = 0;
+            const bool merged = decode_span<MODE_BRIDGE>(tabs, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
+            S.cnt = ndu;
+            if (!merged) {
+                const uint32_t np = p + g.base_bit, ncz = (c << 8) | z;
+                if (np != S.p_img || ncz != S.cz) { S.p_img = np; S.cz = ncz; changed = 1; }
+            }
         }
-        chg[(cur ^ 1) * PJD_HUFF_THREADS + t] = changed;
-        if (!__syncthreads_or((int)changed)) return true;
-        cur ^= 1;
     }
-    return false;
+    return !__any(changed != 0);
 }
 
-// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_sync(PjdDevBatch B)
 {
-    __shared__ HuffLds L;
-    __shared__ uint32_t Ep[PJD_HUFF_THREADS], Ecz[PJD_HUFF_THREADS], Ecnt[PJD_HUFF_THREADS], chg[2 * PJD_HUFF_THREADS];
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const PjdDevHuffWg wg = B.hwgs[w];
     const PjdDevImage &im = B.images[wg.image];
-    LaneGeom g; LaneTables T;
-    wg_setup(B, wg, im, L, g, T, true);
-    const uint32_t nl = im.n_luma, dus = im.dus_per_mcu;
-
-    // round 0: every lane from the start of its own subsequence, state (DC of unit 0 expected)
+    LaneGeom g; uint32_t tpacked; ChkCtx K;
+    wave_setup(B, wg, im, g, tpacked, K);
+    // round 0: every lane from the start of its own subsequence (the true state at a segment start)
     uint32_t p = g.start_bit, c = 0, z = 0, ndu = 0, err = 0, D = 0;
-    if (g.valid) decode_span<false>(L, T, nl, dus, p, c, z, g.end_bit, ndu, err, nullptr, D, 0);
-    Ep[t] = p; Ecz[t] = (c << 8) | z; Ecnt[t] = ndu;
-    chg[t] = g.valid ? 1 : 0;
-    __syncthreads();
-    const bool ok = resync_rounds(L, T, g, nl, dus, Ep, Ecz, Ecnt, chg, B.stats, 0);
+    if (g.valid) decode_span<MODE_SPEC>(pjd_huff_lds, tpacked, im.n_luma, im.dus_per_mcu, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
+    WaveState S = { p + g.base_bit, (c << 8) | z, ndu };
+    const uint64_t entry0 = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);       // lane 0: the assumed entry
+    const bool ok = wave_rounds(im, g, tpacked, K, S, g.valid ? 1u : 0u, B.stats, 0);
     if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
-
     if (g.owned) {
-        B.sub_exit[g.q] = pjd_pack_state(Ep[t] + g.base_bit, Ecz[t] >> 8, Ecz[t] & 255);
-        B.sub_cnt[g.q] = Ecnt[t];
+        B.sub_exit[g.q] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
+        B.sub_cnt[g.q] = S.cnt;
+        // keep the trajectory's checkpoints: a boundary re-stitch (pjd_k_huff_fix) can then bridge
+        // into them instead of repeating the speculative pass
+        uint4 *dst = reinterpret_cast<uint4 *>(B.sub_chk + (size_t)g.q * 2 * PJD_NCHK);
+        for (int h = 0; h < 2; h++) {
+            const uint32_t *src = h ? K.rem : K.state;
+            dst[2 * h] = make_uint4(src[0], src[64], src[128], src[192]);
+            dst[2 * h + 1] = make_uint4(src[256], src[320], src[384], src[448]);
+        }
     }
-    if (t == 0) B.wg_entry[w] = g.valid ? pjd_pack_state(Ep[0] + g.base_bit, Ecz[0] >> 8, Ecz[0] & 255) : ~0ull;
-    if (t == wg.n_sub) B.wg_exit[w] = pjd_pack_state(Ep[t] + g.base_bit, Ecz[t] >> 8, Ecz[t] & 255);
+    if (t == 0) {
+        B.wg_entry[w] = g.valid ? entry0 : ~0ull;
+        // an over-subscribed Huffman table cannot be decoded by length limits: exact kernel
+        uint32_t irr = 0;
+        for (uint32_t k = 0; k < im.n_tables; k++) irr |= *reinterpret_cast<const uint32_t *>(pjd_huff_lds + k * LUT_BYTES + OFF_IRR);
+        if (irr) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
+    }
+    if (t == wg.n_sub) B.wg_exit[w] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,27 +366,17 @@ __device__ __forceinline__ void seg_combine(uint32_t av, uint32_t af, uint32_t &
     bf |= af;
 }
 
-// Inclusive segmented scan over the 256 lanes of a workgroup (wave shuffles + one LDS hop).
-__device__ __forceinline__ void wg_seg_scan(uint32_t &v, uint32_t &f, uint32_t *sv, uint32_t *sf)
+__device__ __forceinline__ void wave_seg_scan(uint32_t &v, uint32_t &f)      // inclusive, 64 lanes
 {
-    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t lane = threadIdx.x & 63;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t ov = __shfl_up(v, off), of = __shfl_up(f, off);
         if ((int)lane >= off) seg_combine(ov, of, v, f);
     }
-    if (lane == 63) { sv[wv] = v; sf[wv] = f; }
-    __syncthreads();
-    uint32_t cv = 0, cf = 0;
-    for (uint32_t k = 0; k < wv; k++) { uint32_t bv = sv[k], bf = sf[k]; seg_combine(cv, cf, bv, bf); cv = bv; cf = bf; }
-    seg_combine(cv, cf, v, f);
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_fix(PjdDevBatch B)
 {
-    __shared__ HuffLds L;
-    __shared__ uint32_t Ep[PJD_HUFF_THREADS], Ecz[PJD_HUFF_THREADS], Ecnt[PJD_HUFF_THREADS], chg[2 * PJD_HUFF_THREADS];
-    __shared__ uint32_t sv[4], sf[4];
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const PjdDevHuffWg wg = B.hwgs[w];
     const PjdDevImage &im = B.images[wg.image];
@@ -336,36 +388,46 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_fix(PjdDevBatch B
         truth = B.wg_exit[w - 1];                    // generation 0: written by pjd_k_huff_sync
         redo = truth != B.wg_entry[w];
     }
-    if (redo) {                                       // workgroup-uniform
-        LaneGeom g; LaneTables T;
-        wg_setup(B, wg, im, L, g, T, true);
-        uint64_t e = g.owned ? B.sub_exit[g.q] : truth;
-        Ep[t] = (uint32_t)e - g.base_bit; Ecz[t] = (((uint32_t)(e >> 32) & 255) << 8) | ((uint32_t)(e >> 40) & 255);
-        Ecnt[t] = g.owned ? B.sub_cnt[g.q] : 0;
-        chg[t] = (t == 0) ? 1 : 0;
-        __syncthreads();
-        const bool ok = resync_rounds(L, T, g, im.n_luma, im.dus_per_mcu, Ep, Ecz, Ecnt, chg, B.stats, 2);
+    uint32_t my_cnt = 0;
+    if (redo) {                                       // wave-uniform: redo this wave from the true entry
+        LaneGeom g; uint32_t tpacked; ChkCtx K;
+        wave_setup(B, wg, im, g, tpacked, K);
+        WaveState S = { 0, 0, 0 };
+        if (g.owned) {
+            const uint64_t e = B.sub_exit[g.q];
+            S.p_img = (uint32_t)e; S.cz = (((uint32_t)(e >> 32) & 255) << 8) | ((uint32_t)(e >> 40) & 255);
+            S.cnt = B.sub_cnt[g.q];
+            const uint4 *src = reinterpret_cast<const uint4 *>(B.sub_chk + (size_t)g.q * 2 * PJD_NCHK);
+            for (int h = 0; h < 2; h++) {
+                uint32_t *dst = h ? K.rem : K.state;
+                const uint4 a = src[2 * h], b = src[2 * h + 1];
+                dst[0] = a.x; dst[64] = a.y; dst[128] = a.z; dst[192] = a.w;
+                dst[256] = b.x; dst[320] = b.y; dst[384] = b.z; dst[448] = b.w;
+            }
+        }
+        if (t == 0) { S.p_img = (uint32_t)truth; S.cz = (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255); S.cnt = 0; }
+        const bool ok = wave_rounds(im, g, tpacked, K, S, t == 0 ? 1u : 0u, B.stats, 2);
         if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
         if (g.owned) {
-            B.sub_exit[g.q] = pjd_pack_state(Ep[t] + g.base_bit, Ecz[t] >> 8, Ecz[t] & 255);
-            B.sub_cnt[g.q] = Ecnt[t];
+            B.sub_exit[g.q] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
+            B.sub_cnt[g.q] = S.cnt;
+            my_cnt = S.cnt;
         }
         if (t == 0) B.wg_entry[w] = truth;
-        if (t == wg.n_sub) exit1[w] = pjd_pack_state(Ep[t] + g.base_bit, Ecz[t] >> 8, Ecz[t] & 255);
-        __syncthreads();
-    } else if (t == 0) {
-        exit1[w] = B.wg_exit[w];
+        if (t == wg.n_sub) exit1[w] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
+    } else {
+        if (t == 0) exit1[w] = B.wg_exit[w];
+        if (t >= 1 && t - 1 < wg.n_sub) my_cnt = B.sub_cnt[wg.first_sub + t - 1];
     }
-    // per-workgroup aggregate of data-unit counts: (absolute index after the last owned lane if a
-    // segment starts inside, else the number of units completed), head flag
+    // per-wave aggregate of data-unit counts: (absolute index after the last owned lane if a segment
+    // starts inside, else the number of units completed), head flag
     uint32_t v = 0, f = 0;
     if (t >= 1 && t - 1 < wg.n_sub) {
-        const uint32_t q = wg.first_sub + t - 1;
-        const uint32_t sg = B.subs[q].seg;
-        v = redo ? Ecnt[t] : B.sub_cnt[q];
+        const uint32_t sg = B.subs[wg.first_sub + t - 1].seg;
+        v = my_cnt;
         if (sg >> 31) { f = 1; v += B.segs[sg & 0x7fffffffu].first_du; }
     }
-    wg_seg_scan(v, f, sv, sf);
+    wave_seg_scan(v, f);
     if (t == PJD_HUFF_THREADS - 1) { B.wg_agg[2 * w] = v; B.wg_agg[2 * w + 1] = f; }
 }
 
@@ -378,10 +440,7 @@ __global__ __launch_bounds__(64) void pjd_k_huff_carry(PjdDevBatch B)
         const uint32_t j = base + lane;
         uint32_t v = 0, f = 0;
         if (j < n) { v = B.wg_agg[2 * (im.hwg_base + j)]; f = B.wg_agg[2 * (im.hwg_base + j) + 1]; }
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t ov = __shfl_up(v, off), of = __shfl_up(f, off);
-            if ((int)lane >= off) seg_combine(ov, of, v, f);
-        }
+        wave_seg_scan(v, f);
         const uint32_t pv = __shfl_up(v, 1), pf = __shfl_up(f, 1);
         uint32_t in = carry;
         if (lane > 0) in = pf ? pv : carry + pv;
@@ -394,17 +453,15 @@ __global__ __launch_bounds__(64) void pjd_k_huff_carry(PjdDevBatch B)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch B)
 {
-    __shared__ HuffLds L;
-    __shared__ uint32_t sv[4], sf[4];
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const PjdDevHuffWg wg = B.hwgs[w];
     const PjdDevImage &im = B.images[wg.image];
-    LaneGeom g; LaneTables T;
-    wg_setup(B, wg, im, L, g, T, true);
+    LaneGeom g; uint32_t tpacked; ChkCtx K;
+    wave_setup(B, wg, im, g, tpacked, K);
     const uint32_t nl = im.n_luma, dus = im.dus_per_mcu;
     const bool first_is_head = (B.subs[wg.first_sub].seg >> 31) != 0;
     uint32_t flag = 0;
-    // the entry this workgroup was synchronised with must be what its predecessor finally produced
+    // the entry this wave was synchronised with must be what its predecessor finally produced
     if (t == 0 && !first_is_head && B.wg_entry[w] != B.wg_exit[B.n_hwg + w - 1]) flag = 1;
 
     // absolute data-unit index at the entry of every owned lane
@@ -416,7 +473,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
         v = cnt;
         if (g.seg_first) { f = 1; v += seg_first_du; }
     }
-    wg_seg_scan(v, f, sv, sf);
+    wave_seg_scan(v, f);
     if (g.owned) {
         const uint32_t D_out = f ? v : B.wg_du_in[w] + v;
         uint32_t D = D_out - cnt;
@@ -430,16 +487,16 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
         }
         uint32_t ndu = 0, err = 0;
         int16_t *coef_img = B.coef + im.du_base * 64;
-        if (D_in < D_end || g.seg_last) {
-            decode_span<true>(L, T, nl, dus, p, c, z, g.end_bit, ndu, err, coef_img, D, D_end);
+        if (D_in < D_end) {
+            decode_span<MODE_WRITE>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, coef_img, D, D_end);
             if (err) flag = 1;
-            if (D == D_end && D_in < D_end) {
+            if (D == D_end) {
                 // this lane completed the segment: the reference's BitReader must be able to reach
                 // the next segment by align() alone, and must not have read past the data
                 if (p > g.seg_end_bit) flag = 1;
                 const bool has_next = g.seg + 1 < im.seg_base + im.n_seg;
                 if (has_next && ((p + 7) & ~7u) != g.seg_end_bit) flag = 1;
-            } else if (D < D_end) {
+            } else {
                 // stopped at the subsequence end: must reproduce the synchronised exit state
                 const uint64_t e = B.sub_exit[g.q];
                 if ((uint32_t)e - g.base_bit != p || ((uint32_t)(e >> 32) & 255) != c || ((uint32_t)(e >> 40) & 255) != z) flag = 1;
@@ -451,6 +508,8 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
 }
 
 // ---------------------------------------------------------------------------------------------
+static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_tables * LUT_BYTES + 2 * PJD_NCHK * 64 * sizeof(uint32_t); }
+
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 {
     if (b.n_images == 0) return;
@@ -458,11 +517,11 @@ void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 }
 void pjd_launch_huff_sync(hipStream_t s, const PjdDevBatch &b)
 {
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_sync, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), 0, s, b);
+    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_sync, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
 }
 void pjd_launch_huff_fix(hipStream_t s, const PjdDevBatch &b)
 {
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_fix, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), 0, s, b);
+    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_fix, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
 }
 void pjd_launch_huff_carry(hipStream_t s, const PjdDevBatch &b)
 {
@@ -470,5 +529,5 @@ void pjd_launch_huff_carry(hipStream_t s, const PjdDevBatch &b)
 }
 void pjd_launch_huff_write(hipStream_t s, const PjdDevBatch &b)
 {
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_write, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), 0, s, b);
+    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_write, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
 }

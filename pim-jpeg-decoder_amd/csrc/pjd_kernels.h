@@ -22,6 +22,7 @@ struct PjdDevBatch {
     // Huffman synchronisation scratch
     uint64_t *sub_exit;                  // per subsequence: packed state at its end
     uint32_t *sub_cnt;                   // per subsequence: data units completed inside it
+    uint32_t *sub_chk;                   // per subsequence: PJD_NCHK checkpoint states + PJD_NCHK "units still to come"
     uint64_t *wg_entry;                  // per Huffman workgroup: entry state it assumed for its first owned subsequence
     uint64_t *wg_exit;                   // [2][n_hwg]: exit state of its last owned subsequence, generation 0/1
     uint32_t *wg_agg;                    // per Huffman workgroup: {value, has_head}
@@ -32,6 +33,8 @@ struct PjdDevBatch {
     const uint32_t *dcblk_image;         // per DC block: owning image
     unsigned long long *stats;           // [8] diagnostics: 0 sync rounds, 1 lane-passes in sync, 2 fix rounds, 3 lane-passes in fix
     uint32_t n_images, n_hwg, n_iwg, n_dcblk;
+    uint32_t sub_bytes;                  // Huffman subsequence size of this batch
+    uint32_t max_tables;                 // largest n_tables in the batch (sizes the dynamic LDS of the Huffman kernels)
 };
 
 // ---- back end (pjd_k_backend.hip) ------------------------------------------------

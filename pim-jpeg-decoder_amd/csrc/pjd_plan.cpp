@@ -34,7 +34,8 @@ extern "C" uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_for
     return (uint64_t)width * height * 3;
 }
 
-int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &P, std::string &err)
+int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &P, std::string &err,
+                  uint32_t sub_bytes_override)
 {
     if (n < 0 || (n > 0 && !images)) { err = "null image array"; return PJD_E_ARG; }
     if (out_format != PJD_OUT_RGB8 && out_format != PJD_OUT_BMP) { err = "unknown output format"; return PJD_E_ARG; }
@@ -44,6 +45,24 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.host.resize(n);
     P.tables.assign((size_t)n * PJD_MAX_TABLES, PjdDevHuffRaw());
     P.qtab.assign((size_t)n * 3 * 64, 0);
+
+    // Subsequence size.  The self-synchronisation distance of a 4:2:0 stream is ~160 B on average
+    // with 5 % above 512 B (bit position, zigzag slot AND the 6-unit MCU phase must all match), so
+    // lanes should be several times that long; but a small batch needs enough lanes to fill 256 CUs.
+    {
+        uint64_t total = 0;
+        for (int i = 0; i < n; i++) total += images[i].ecs_len;
+        uint32_t sb = total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u);
+        if (sub_bytes_override) {
+            if (sub_bytes_override < PJD_SUB_BYTES_MIN || sub_bytes_override > PJD_SUB_BYTES_MAX || (sub_bytes_override & (sub_bytes_override - 1))) {
+                err = "sub_bytes override must be a power of two in [128, 1024]";
+                return PJD_E_ARG;
+            }
+            sb = sub_bytes_override;
+        }
+        P.sub_bytes = sb;
+    }
+    const uint32_t SB = P.sub_bytes;
 
     uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0;
     for (int i = 0; i < n; i++) {
@@ -156,7 +175,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         h.ecs_copy_len = byte_hi - byte_lo;
         g.ecs_len = (uint32_t)h.ecs_copy_len;
         g.ecs_off = ecs_off;
-        ecs_off = align_up(ecs_off + h.ecs_copy_len + 16, 16);   // >= 16 zero bytes after every stream
+        ecs_off = align_up(ecs_off + h.ecs_copy_len + 48, 16);   // >= 48 zero bytes after every stream (lane prefetch reads ahead)
 
         g.seg_base = (uint32_t)P.segs.size();
         g.sub_base = (uint32_t)P.subs.size();
@@ -175,10 +194,10 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                 const uint32_t seg_index = (uint32_t)P.segs.size();
                 P.segs.push_back(s);
                 uint32_t len = s.byte_end - s.byte_start;
-                uint32_t nsub = len ? (len + PJD_SUBSEQ_BYTES - 1) / PJD_SUBSEQ_BYTES : 1;
+                uint32_t nsub = len ? (len + SB - 1) / SB : 1;
                 for (uint32_t j = 0; j < nsub; j++) {
                     PjdDevSub q;
-                    q.byte_start = s.byte_start + j * PJD_SUBSEQ_BYTES;
+                    q.byte_start = s.byte_start + j * SB;
                     q.seg = seg_index | (j == 0 ? 0x80000000u : 0u);
                     P.subs.push_back(q);
                 }

@@ -15,6 +15,7 @@ struct PjdHostImage {
 
 struct PjdPlan {
     int out_format = 0;
+    uint32_t sub_bytes = 512;              // Huffman subsequence size chosen for this batch
     std::vector<PjdDevImage> images;
     std::vector<PjdHostImage> host;
     std::vector<PjdDevHuffRaw> tables;     // n_images * PJD_MAX_TABLES
@@ -33,4 +34,6 @@ struct PjdPlan {
 };
 
 // Returns PJD_OK or PJD_E_ARG (with a message in `err`).
-int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &plan, std::string &err);
+// sub_bytes_override: 0 = choose from the batch size, else a power of two in [PJD_SUB_BYTES_MIN, PJD_SUB_BYTES_MAX].
+int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &plan, std::string &err,
+                  uint32_t sub_bytes_override = 0);
