@@ -73,6 +73,7 @@ struct pjd_batch {
     PjdDevSub *d_subs = nullptr;
     PjdDevHuffWg *d_hwgs = nullptr;
     PjdDevIdctWg *d_iwgs = nullptr;
+    PjdDevIdctWg *d_iwgs_dense = nullptr;
     uint8_t *d_ecs = nullptr;
     uint32_t *d_dcblk_image = nullptr;
     uint32_t *d_seq_list = nullptr;      // images routed to the exact kernel up front
@@ -151,7 +152,8 @@ void pjd_batch_destroy(pjd_batch *b)
     hipStreamSynchronize(b->ctx->stream);
     if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
     if (b->graph) hipGraphDestroy(b->graph);
-    void *ptrs[] = { b->d_images, b->d_raw, b->d_qtab, b->d_segs, b->d_subs, b->d_hwgs, b->d_iwgs, b->d_ecs,
+    void *ptrs[] = { b->d_images, b->d_raw, b->d_qtab, b->d_segs, b->d_subs, b->d_hwgs, b->d_iwgs, b->d_iwgs_dense, b->d_ecs,
+                     b->dev.ent, b->dev.du_end, b->dev.seg_ent, b->dev.dcv, b->dev.wg_eagg, b->dev.wg_ent_in,
                      b->d_dcblk_image, b->d_seq_list, b->d_fb_list, b->d_fb_iwgs, b->d_status_init,
                      b->dev.luts, b->dev.coef, b->dev.out, b->dev.status, b->dev.sub_exit, b->dev.sub_cnt, b->dev.sub_chk,
                      b->dev.wg_entry, b->dev.wg_exit, b->dev.wg_agg, b->dev.wg_du_in, b->dev.dc_agg, b->dev.dc_carry, b->dev.stats };
@@ -198,6 +200,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->d_subs, P.subs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_hwgs, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_iwgs, P.iwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_iwgs_dense, P.iwgs_dense.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_fb_iwgs, P.iwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_ecs, P.ecs_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->d_dcblk_image, P.n_dcblk, tot));
@@ -205,7 +208,13 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->d_fb_list, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->d_status_init, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->dev.luts, P.tables.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.coef, P.n_du * 64, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.coef, P.dense_du * 64, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.ent, P.n_ent, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.du_end, P.n_du, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.seg_ent, P.segs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.dcv, P.n_du, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.wg_eagg, P.hwgs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.wg_ent_in, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.out, P.out_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->dev.sub_exit, P.subs.size(), tot));
@@ -217,7 +226,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.wg_du_in, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_agg, P.n_dcblk * 4, tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_carry, P.n_dcblk * 4, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.stats, 8, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.stats, 16, tot));
 #undef TRY_RC
     b->dev.images = b->d_images; b->dev.raw_tables = b->d_raw; b->dev.qtab = b->d_qtab;
     b->dev.segs = b->d_segs; b->dev.subs = b->d_subs; b->dev.hwgs = b->d_hwgs; b->dev.iwgs = b->d_iwgs;
@@ -240,7 +249,7 @@ int pjd_batch_upload(pjd_batch *b)
     hipStream_t s = ctx->stream;
 #define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(ctx, hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, s)); } while (0)
     UP(b->d_images, P.images); UP(b->d_raw, P.tables); UP(b->d_qtab, P.qtab);
-    UP(b->d_segs, P.segs); UP(b->d_subs, P.subs); UP(b->d_hwgs, P.hwgs); UP(b->d_iwgs, P.iwgs);
+    UP(b->d_segs, P.segs); UP(b->d_subs, P.subs); UP(b->d_hwgs, P.hwgs); UP(b->d_iwgs, P.iwgs); UP(b->d_iwgs_dense, P.iwgs_dense);
     std::vector<uint32_t> dcimg(P.n_dcblk);
     for (size_t i = 0; i < P.images.size(); i++)
         for (uint32_t k = 0; k < P.images[i].n_dcblk; k++) dcimg[P.images[i].dcblk_base + k] = (uint32_t)i;
@@ -248,10 +257,6 @@ int pjd_batch_upload(pjd_batch *b)
     // routing: images for the exact kernel, and the initial status words
     b->seq_list = P.seq_images;
     std::vector<int32_t> st0(P.images.size(), 0);
-    if (ctx->force_sequential) {
-        b->seq_list.clear();
-        for (size_t i = 0; i < P.images.size(); i++) b->seq_list.push_back((uint32_t)i);
-    }
     for (uint32_t i : b->seq_list) st0[i] = PJD_STW_NEEDS_EXACT;
     UP(b->d_seq_list, b->seq_list);
     UP(b->d_status_init, st0);
@@ -306,12 +311,11 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     PjdPlan &P = b->plan;
     hipStream_t s = ctx->stream;
     KernelTimer kt{timings, s, {}, {}};
-    const bool parallel = !ctx->force_sequential && !P.hwgs.empty();
+    const bool parallel = !P.hwgs.empty();
     kt.mark("start");
     HIP_TRY(ctx, hipMemcpyAsync(b->dev.status, b->d_status_init, sizeof(int32_t) * P.images.size(), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, P.n_du * 64 * sizeof(int16_t), s));
-    HIP_TRY(ctx, hipMemsetAsync(b->dev.stats, 0, 8 * sizeof(unsigned long long), s));
-    kt.mark("memset_coef");
+    HIP_TRY(ctx, hipMemsetAsync(b->dev.stats, 0, 16 * sizeof(unsigned long long), s));
+    kt.mark("reset");
     if (parallel) {
         pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
         pjd_launch_huff_sync(s, b->dev);     kt.mark("huff_sync");
@@ -319,13 +323,18 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
         pjd_launch_huff_carry(s, b->dev);    kt.mark("huff_carry");
         pjd_launch_huff_write(s, b->dev);    kt.mark("huff_write");
         pjd_launch_dc_scan(s, b->dev);       kt.mark("dc_scan");
+        pjd_launch_idct_colour_sparse(s, b->dev, b->d_iwgs, (uint32_t)P.iwgs.size());
+        kt.mark("idct_colour");
     }
     if (!b->seq_list.empty()) {
+        // images routed to the exact kernel: dense int16 scratch, cleared first (unvisited slots are zero)
+        uint64_t seq_du = 0;
+        for (uint32_t i : b->seq_list) seq_du += P.images[i].n_du;
+        HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, seq_du * 64 * sizeof(int16_t), s));
         pjd_launch_huff_sequential(s, b->dev, b->d_seq_list, (uint32_t)b->seq_list.size());
-        kt.mark("huff_sequential");
+        pjd_launch_idct_colour(s, b->dev, b->d_iwgs_dense, (uint32_t)P.iwgs_dense.size());
+        kt.mark("exact_path");
     }
-    pjd_launch_idct_colour(s, b->dev, b->d_iwgs, (uint32_t)P.iwgs.size());
-    kt.mark("idct_colour");
     HIP_TRY(ctx, hipGetLastError());
     kt.finish();
     b->decoded = true;
@@ -350,21 +359,20 @@ int settle(pjd_batch *b)
     for (size_t i = 0; i < n; i++)
         if ((b->h_status[i] & PJD_STW_NEEDS_EXACT) && !was_seq[i]) fb.push_back((uint32_t)i);
     b->n_fallback = (int)fb.size();
-    if (!fb.empty()) {
-        std::vector<PjdDevIdctWg> wl;
-        for (uint32_t i : fb) {
-            if (P.images[i].first_mcu != 0 || P.images[i].last_mcu != P.images[i].n_mcu) {
-                ctx->err = "a sharded image needs the exact kernel (irregular restart segment)";
-                return PJD_E_ARG;
-            }
-            HIP_TRY(ctx, hipMemsetAsync(b->dev.coef + P.images[i].du_base * 64, 0, (size_t)P.images[i].n_du * 64 * sizeof(int16_t), s));
-            for (uint32_t k = 0; k < b->iwg_count[i]; k++) wl.push_back(P.iwgs[b->iwg_base[i] + k]);
+    for (uint32_t i : fb) {
+        // one image at a time through the shared dense scratch (stream order keeps them apart)
+        if (P.images[i].first_mcu != 0 || P.images[i].last_mcu != P.images[i].n_mcu) {
+            ctx->err = "a sharded image needs the exact kernel (irregular restart segment)";
+            return PJD_E_ARG;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_fb_list, fb.data(), fb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_fb_iwgs, wl.data(), wl.size() * sizeof(PjdDevIdctWg), hipMemcpyHostToDevice, s));
-        pjd_launch_huff_sequential(s, b->dev, b->d_fb_list, (uint32_t)fb.size());
-        pjd_launch_idct_colour(s, b->dev, b->d_fb_iwgs, (uint32_t)wl.size());
+        HIP_TRY(ctx, hipMemsetAsync(b->dev.coef + P.images[i].dense_base * 64, 0, (size_t)P.images[i].n_du * 64 * sizeof(int16_t), s));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_fb_list, &i, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));      // `i` is a stack variable
+        pjd_launch_huff_sequential(s, b->dev, b->d_fb_list, 1);
+        pjd_launch_idct_colour(s, b->dev, b->d_iwgs + b->iwg_base[i], b->iwg_count[i]);
         HIP_TRY(ctx, hipGetLastError());
+    }
+    if (!fb.empty()) {
         HIP_TRY(ctx, hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
     }
@@ -449,17 +457,20 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     std::memset(info, 0, sizeof *info);
     info->n_images = (int32_t)P.images.size();
     info->pixels = P.pixels; info->ecs_bytes = P.ecs_bytes; info->out_bytes = P.out_bytes;
-    info->coef_bytes = P.n_du * 64 * sizeof(int16_t);
+    info->coef_bytes = P.n_ent * 4 + P.n_du * 6 + P.dense_du * 128;
     info->n_data_units = P.n_du;
     info->n_subsequences = P.subs.size();
     info->device_bytes = b->device_bytes;
     info->n_sequential = (int32_t)b->seq_list.size();
     info->n_fallback = b->n_fallback;
-    unsigned long long st[8] = {0};
+    unsigned long long st[16] = {0};
     if (b->decoded && hipMemcpy(st, b->dev.stats, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
         info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
     }
     info->n_huff_workgroups = P.hwgs.size();
+    if (std::getenv("PJD_DEBUG_STATS"))
+        std::fprintf(stderr, "[pjd stats] setup_cyc %llu round0_cyc %llu rounds_cyc %llu round0_maxiters %llu | realtime(10ns) setup %llu round0 %llu rounds %llu | waves %zu\n",
+                     st[4], st[5], st[6], st[7], st[8], st[9], st[10], P.hwgs.size());
     return PJD_OK;
 }
 

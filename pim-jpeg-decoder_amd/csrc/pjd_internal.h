@@ -39,8 +39,11 @@ struct PjdDevImage {
     uint32_t ref_mcu_w, ref_mcu_h, ref_mcu_w_real;   // reference Header::mcu_width / mcu_height / mcu_width_real
     uint32_t ecs_len;                  // bytes
     uint64_t ecs_off;                  // into the batch bitstream buffer (16-byte aligned)
-    uint64_t du_base;                  // first data unit of this image in the coefficient buffer
+    uint64_t du_base;                  // first data unit of this image in the per-unit arrays (dcv, and du_off at du_base + image index)
+    uint64_t ent_base;                 // first entry of this image in the coefficient-entry stream
+    uint64_t dense_base;               // first data unit of this image in the DENSE scratch (exact-kernel path only)
     uint32_t n_du;
+    uint32_t image_index;
     uint32_t out_stride;               // bytes per output row (BMP: 3W + W%4, RGB8: 3W)
     uint64_t out_off;                  // into the batch output buffer (256-byte aligned)
     uint32_t seg_base, n_seg;          // into PjdDevSegment[]
@@ -50,7 +53,7 @@ struct PjdDevImage {
     uint32_t first_mcu, last_mcu;      // MCU range this shard decodes: [first_mcu, last_mcu)
     uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1
     uint8_t  n_tables;
-    uint8_t  pad_[9];
+    uint8_t  pad_[1];
 };
 
 // raw Huffman table as shipped by the host (reference HuffmanTable, jpeg.h:129-134)

@@ -4,9 +4,11 @@
 //                       (reference src/decoder_dpu.c:82-390)
 //   pjd_k_dc_local /    DC prediction as a two-level segmented scan over MCUs
 //   pjd_k_dc_carry      (reference src/jpeg_scanner.cpp:485-486,723-727)
-//   pjd_k_idct_colour   fused de-zigzag + dequantise + 8x8 IDCT + chroma upsample +
-//                       YCbCr->RGB + raster store (reference src/decoder_dpu.c:158-390 and
-//                       src/bmp_writer.cpp:43-65 for the BMP row order)
+//   pjd_k_idct_colour_sparse / pjd_k_idct_colour
+//                       fused de-zigzag + dequantise + 8x8 IDCT + chroma upsample + YCbCr->RGB +
+//                       raster store (reference src/decoder_dpu.c:158-390 and src/bmp_writer.cpp:43-65
+//                       for the BMP row order).  _sparse reads the parallel decoder's entry stream;
+//                       the other reads the dense int16 scratch the exact kernel fills.
 //
 // HBM-bound integer work: coefficients are read once with 16-byte loads, tiles
 // live in LDS (row stride 144 B so that the column pass is bank-conflict free),
@@ -83,8 +85,8 @@ void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mc
 }
 
 // ---------------------------------------------------------------------------------------------
-// DC prediction.  After the parallel entropy decode, slot 0 of every data unit holds the DC
-// DIFFERENCE.  Level 1: each workgroup takes PJD_DC_BLOCK MCUs of one image, scans the
+// DC prediction.  After the parallel entropy decode, dcv[] holds the DC DIFFERENCE of every data
+// unit.  Level 1: each workgroup takes PJD_DC_BLOCK MCUs of one image, scans the
 // per-component sums with resets at restart points, and rewrites slot 0 with the prediction
 // relative to the block start.  Level 2: one wave per image scans the block aggregates.  The
 // IDCT kernel adds the carry.  All sums are modulo 2^16 like the reference's `short` stores.
@@ -106,14 +108,14 @@ __global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_dc_local(PjdDevBatch B)
     const uint32_t m = (b - im.dcblk_base) * PJD_DC_BLOCK + tid;
     const bool live = m >= im.first_mcu && m < im.last_mcu;
     const uint32_t RI = im.restart_interval, dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp;
-    int16_t *du0 = B.coef + (im.du_base + (uint64_t)m * dus) * 64;
+    int16_t *du0 = B.dcv + im.du_base + (uint64_t)m * dus;
     uint32_t d[6] = {0, 0, 0, 0, 0, 0};     // fully unrolled below: stays in registers
     uint32_t vy = 0, vcb = 0, vcr = 0, head = 0;
     if (live) {
 #pragma unroll
         for (uint32_t k = 0; k < 6; k++)
             if (k < dus) {
-                const uint32_t dv = (uint32_t)(int32_t)du0[k * 64];
+                const uint32_t dv = (uint32_t)(int32_t)du0[k];
                 d[k] = dv;
                 if (k < nl) vy += dv; else if (k == nl) vcb = dv; else vcr = dv;
             }
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_dc_local(PjdDevBatch B)
                 if (k < nl) { py += d[k]; val = py; }
                 else if (k == nl) val = pcb + d[k];
                 else val = pcr + d[k];
-                du0[k * 64] = (int16_t)val;
+                du0[k] = (int16_t)val;
             }
     }
     if (tid == PJD_DC_BLOCK - 1) { agg[0] = sy[tid]; agg[1] = scb[tid]; agg[2] = scr[tid]; agg[3] = sf[tid]; }
@@ -183,71 +185,13 @@ __global__ __launch_bounds__(64) void pjd_k_dc_carry(PjdDevBatch B)
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused back end.  One workgroup = up to 96 data units = a run of consecutive MCUs of one image.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
+// Row pass, column pass, chroma upsample + colour + raster store for the data units staged in `tile`
+// (natural order, dequantised).  Shared by the sparse and the dense front ends.
+__device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE], const PjdDevBatch &B, const PjdDevImage &im,
+                                                   const PjdDevIdctWg &wg, uint32_t tid)
 {
-    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
-    __shared__ uint16_t qs[3][64];
-
-    const PjdDevIdctWg wg = wgs[blockIdx.x];
-    const PjdDevImage &im = B.images[wg.image];
-    const uint32_t tid = threadIdx.x;
     const uint32_t dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp, hs = im.hs, vs = im.vs;
     const uint32_t n_du = wg.n_mcu * dus;
-    const uint32_t RI = im.restart_interval;
-    const bool dc_abs = (im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT);
-
-    if (tid < 192) qs[tid >> 6][tid & 63] = B.qtab[(size_t)wg.image * 192 + tid];
-    __syncthreads();
-
-    // ---- load (16 B per lane, coalesced), DC fix-up, de-zigzag, dequantise, row pass ----------
-    // lane (du, r) owns zigzag slots 8r..8r+7 on load; after the scatter to natural order a
-    // second sweep does the row pass.
-    const int16_t *cbase = B.coef + (im.du_base + (uint64_t)wg.first_mcu * dus) * 64;
-    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
-        const uint32_t du = i >> 3, r = i & 7;
-        const uint32_t ml = du / dus, k = du - ml * dus;
-        const uint32_t comp = k < nl ? 0 : k - nl + 1;
-        const int4 raw = *reinterpret_cast<const int4 *>(cbase + (size_t)du * 64 + r * 8);
-        const int16_t *rv = reinterpret_cast<const int16_t *>(&raw);
-        int v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = rv[j];
-        if (r == 0 && !dc_abs) {
-            const uint32_t m = wg.first_mcu + ml;
-            const uint32_t blk = m / PJD_DC_BLOCK;
-            const uint32_t hm = RI ? (m / RI) * RI : 0;      // last restart point at or before m
-            if (hm < blk * PJD_DC_BLOCK) {                    // none inside this scan block: carry applies
-                const uint32_t *c = B.dc_carry + (size_t)(im.dcblk_base + blk) * 4;
-                v[0] = (int)(int16_t)((uint32_t)v[0] + c[comp]);
-            }
-        }
-        int16_t *t = tile[du];
-        const uint16_t *q = qs[comp];
-        if (r == 6) {
-            // slots 48..55.  Natural position 38 is the target of slot 48 AND slot 52 (the
-            // reference's zigzag_map[48] = 38): the later write wins, and an explicit zero
-            // written at slot 52 (run/size symbol with size 0) is marked by the sentinel.
-            const int v52 = v[4];
-            const int n38 = v52 != 0 ? (v52 == PJD_COEF_SENTINEL ? 0 : v52) : v[0];
-            t[38] = (int16_t)pjd_dequant(n38, q[38]);
-            t[59] = (int16_t)pjd_dequant(v[1], q[59]);
-            t[52] = (int16_t)pjd_dequant(v[2], q[52]);
-            t[45] = (int16_t)pjd_dequant(v[3], q[45]);
-            t[31] = (int16_t)pjd_dequant(v[5], q[31]);
-            t[39] = (int16_t)pjd_dequant(v[6], q[39]);
-            t[46] = (int16_t)pjd_dequant(v[7], q[46]);
-            t[58] = 0;                    // natural 58 is never written by the reference
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t nat = c_zz[r * 8 + j];
-                t[nat] = (int16_t)pjd_dequant(v[j], q[nat]);
-            }
-        }
-    }
     __syncthreads();
     for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {      // rows
         const uint32_t du = i >> 3, r = i & 7;
@@ -315,6 +259,147 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
             o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused back end.  One workgroup = up to 96 data units = a run of consecutive MCUs of one image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
+    __shared__ uint16_t qs[3][64];
+
+    const PjdDevIdctWg wg = wgs[blockIdx.x];
+    const PjdDevImage &im = B.images[wg.image];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp, hs = im.hs, vs = im.vs;
+    const uint32_t n_du = wg.n_mcu * dus;
+    const uint32_t RI = im.restart_interval;
+
+    if (tid < 192) qs[tid >> 6][tid & 63] = B.qtab[(size_t)wg.image * 192 + tid];
+    __syncthreads();
+
+    // ---- load (16 B per lane, coalesced), DC fix-up, de-zigzag, dequantise, row pass ----------
+    // lane (du, r) owns zigzag slots 8r..8r+7 on load; after the scatter to natural order a
+    // second sweep does the row pass.
+    const int16_t *cbase = B.coef + (im.dense_base + (uint64_t)wg.first_mcu * dus) * 64;
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
+        const uint32_t du = i >> 3, r = i & 7;
+        const uint32_t ml = du / dus, k = du - ml * dus;
+        const uint32_t comp = k < nl ? 0 : k - nl + 1;
+        const int4 raw = *reinterpret_cast<const int4 *>(cbase + (size_t)du * 64 + r * 8);
+        const int16_t *rv = reinterpret_cast<const int16_t *>(&raw);
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = rv[j];
+        int16_t *t = tile[du];
+        const uint16_t *q = qs[comp];
+        if (r == 6) {
+            // slots 48..55.  Natural position 38 is the target of slot 48 AND slot 52 (the
+            // reference's zigzag_map[48] = 38): the later write wins, and an explicit zero
+            // written at slot 52 (run/size symbol with size 0) is marked by the sentinel.
+            const int v52 = v[4];
+            const int n38 = v52 != 0 ? (v52 == PJD_COEF_SENTINEL ? 0 : v52) : v[0];
+            t[38] = (int16_t)pjd_dequant(n38, q[38]);
+            t[59] = (int16_t)pjd_dequant(v[1], q[59]);
+            t[52] = (int16_t)pjd_dequant(v[2], q[52]);
+            t[45] = (int16_t)pjd_dequant(v[3], q[45]);
+            t[31] = (int16_t)pjd_dequant(v[5], q[31]);
+            t[39] = (int16_t)pjd_dequant(v[6], q[39]);
+            t[46] = (int16_t)pjd_dequant(v[7], q[46]);
+            t[58] = 0;                    // natural 58 is never written by the reference
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t nat = c_zz[r * 8 + j];
+                t[nat] = (int16_t)pjd_dequant(v[j], q[nat]);
+            }
+        }
+    }
+    __syncthreads();
+    pjd_tile_to_pixels(tile, B, im, wg, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse front end: the parallel entropy decoder leaves, per data unit, a run of 4-byte entries
+// (value << 16 | zigzag slot, AC only) delimited by du_end[] / seg_ent[], and the DC in dcv[].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
+    __shared__ uint16_t qs[3][64];
+    __shared__ uint32_t e_lo[PJD_IDCT_MAX_DU], e_hi[PJD_IDCT_MAX_DU], s52[PJD_IDCT_MAX_DU];
+    __shared__ uint8_t zzs[64];
+
+    const PjdDevIdctWg wg = wgs[blockIdx.x];
+    const PjdDevImage &im = B.images[wg.image];
+    if ((im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT)) return;   // the dense path redoes it
+    const uint32_t tid = threadIdx.x;
+    const uint32_t dus = im.dus_per_mcu, nl = im.n_luma;
+    const uint32_t n_du = wg.n_mcu * dus;
+    const uint32_t RI = im.restart_interval;
+    const uint32_t d0 = wg.first_mcu * dus;                     // image-relative index of the first unit
+
+    if (tid < 192) qs[tid >> 6][tid & 63] = B.qtab[(size_t)wg.image * 192 + tid];
+    if (tid < 64) zzs[tid] = c_zz[tid];
+    {   // clear the tile: unvisited positions are zero (the reference's buffers start zeroed)
+        uint4 *tz = reinterpret_cast<uint4 *>(&tile[0][0]);
+        const uint32_t n16 = n_du * (TILE_STRIDE * 2 / 16);
+        for (uint32_t i = tid; i < n16; i += PJD_IDCT_THREADS) tz[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid < n_du) {
+        const uint32_t d = d0 + tid, m = d / dus, k = d - m * dus;
+        const bool seg_first = k == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
+        const uint32_t seg = im.seg_base + (RI ? m / RI - im.first_mcu / RI : 0);
+        const uint32_t *de = B.du_end + im.du_base;
+        e_lo[tid] = seg_first ? B.seg_ent[seg] : de[d - 1];
+        e_hi[tid] = de[d];
+        s52[tid] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t *ent = B.ent + im.ent_base;
+    const int16_t *dcv = B.dcv + im.du_base + d0;
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
+        const uint32_t du = i >> 3, r = i & 7;
+        const uint32_t ml = du / dus, k = du - ml * dus;
+        const uint32_t comp = k < nl ? 0 : k - nl + 1;
+        const uint16_t *q = qs[comp];
+        int16_t *t = tile[du];
+        if (r == 0) {
+            int dc = dcv[du];
+            const uint32_t m = wg.first_mcu + ml;
+            const uint32_t blk = m / PJD_DC_BLOCK;
+            const uint32_t hm = RI ? (m / RI) * RI : 0;          // last restart point at or before m
+            if (hm < blk * PJD_DC_BLOCK) {                        // none inside this scan block: carry applies
+                const uint32_t *c = B.dc_carry + (size_t)(im.dcblk_base + blk) * 4;
+                dc = (int)(int16_t)((uint32_t)dc + c[comp]);
+            }
+            t[0] = (int16_t)pjd_dequant(dc, q[0]);
+        }
+        const uint32_t hi = e_hi[du];
+        for (uint32_t e = e_lo[du] + r; e < hi; e += 8) {
+            const uint32_t w = ent[e];
+            const uint32_t slot = w & 63;
+            const int val = (int)(int16_t)(w >> 16);
+            if (slot == 52) s52[du] = 0x80000000u | (w >> 16);     // overrides slot 48 at natural 38, even when zero
+            else { const uint32_t nat = zzs[slot]; t[nat] = (int16_t)pjd_dequant(val, q[nat]); }
+        }
+    }
+    __syncthreads();
+    if (tid < n_du && s52[tid]) {
+        const uint32_t ml = tid / dus, k = tid - ml * dus;
+        const uint32_t comp = k < nl ? 0 : k - nl + 1;
+        tile[tid][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[tid] & 0xffffu), qs[comp][38]);
+    }
+    __syncthreads();
+    pjd_tile_to_pixels(tile, B, im, wg, tid);
+}
+
+void pjd_launch_idct_colour_sparse(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)
+{
+    if (n_wg == 0) return;
+    hipLaunchKernelGGL(pjd_k_idct_colour_sparse, dim3(n_wg), dim3(PJD_IDCT_THREADS), 0, s, b, wgs);
 }
 
 void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)

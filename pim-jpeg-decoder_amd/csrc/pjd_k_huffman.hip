@@ -27,9 +27,11 @@
 //   pjd_k_huff_fix       stitches wave boundaries (overlap lane's guess vs the predecessor wave's
 //                        truth; a mismatching wave is redone) and reduces per-wave unit counts
 //   pjd_k_huff_carry     one wave per image: scan of those counts -> absolute data-unit index
-//   pjd_k_huff_write     final pass from the now-known entry states: coefficients are written, in
-//                        zigzag-slot order, to coef[(du_base + D) * 64 + slot]; slot 0 holds the
-//                        DC DIFFERENCE (pjd_k_dc_* integrates it)
+//   pjd_k_huff_write     final pass from the now-known entry states.  Output is COMPACT: every non-zero
+//                        AC coefficient becomes one 4-byte entry (value << 16 | zigzag slot) in a stream
+//                        whose per-lane offsets are exact prefix sums, so lanes append 16 bytes at a time
+//                        and nothing has to be zero-filled; DC differences go to a dense int16 array
+//                        (pjd_k_dc_* integrates it); du_end[] / seg_ent[] delimit each unit's entries
 //
 // Exactness: a lane that starts from the true state performs exactly the reference's
 // decode_MCU_component (reference src/jpeg_scanner.cpp:467-520).  Anything irregular seen in the
@@ -147,6 +149,15 @@ struct BitWin {
 
 enum { MODE_SPEC = 0, MODE_BRIDGE = 1, MODE_WRITE = 2 };
 
+struct OutCtx {            // WRITE mode: where this lane's output goes
+    uint32_t *ent;         // image's entry stream
+    uint32_t *du_end;      // image's per-unit "end of entries" (image-relative entry index)
+    int16_t *dcv;          // image's per-unit DC differences
+    uint32_t epos;         // next entry index (image-relative)
+    uint32_t epos0;        // entry index this lane started at
+    uint4 acc;             // up to 4 pending entries, newest in .w
+};
+
 struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided by lane)
     uint32_t *state;       // [PJD_NCHK][64] at this lane's column
     uint32_t *rem;         // [PJD_NCHK][64]
@@ -161,8 +172,10 @@ template <int MODE>
 __device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacked, uint32_t nl, uint32_t dus,
                                             const uint4 *base16, uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                             uint32_t &ndu, uint32_t &err, const ChkCtx &K,
-                                            int16_t *coef_img, uint32_t &D, uint32_t D_end)
+                                            OutCtx *O, uint32_t &D, uint32_t D_end)
 {
+    // `ndu` is a packed counter: data units completed in the low 16 bits, AC entries produced in the
+    // high 16 bits (both fit for a subsequence of <= 1024 bytes)
     if (p >= end_bit) return false;
     BitWin w;
     w.init(base16, p);
@@ -210,19 +223,43 @@ __device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacke
         const uint32_t z_ac = (eob || over) ? 64u : zr + 1;
         const uint32_t znew = is_dc ? 1u : z_ac;
         err |= is_dc ? (sym > 11) : (!eob && (over || size > 10));
+        // an AC symbol that stores something: a non-zero coefficient, or the explicit zero at slot 52
+        // (the reference's zigzag_map sends slots 48 and 52 to the same natural position: DESIGN.md)
+        const bool store_ac = !is_dc && !eob && !over && (size != 0 || zr == 52);
+        const bool done = znew >= 64;
         if (MODE == MODE_WRITE) {
             const uint32_t bits = size ? ((pk << len) >> (32 - size)) : 0;
             int val = (int)bits;
             if (size && !(bits >> (size - 1))) val -= (int)((1u << size) - 1);
-            const uint32_t slot = is_dc ? 0u : zr;
-            const bool store = is_dc || (!eob && !over && (size != 0 || zr == 52));
-            if (store) coef_img[(size_t)D * 64 + slot] = (size == 0 && !is_dc) ? (int16_t)PJD_COEF_SENTINEL : (int16_t)val;
+            if (is_dc) O->dcv[D] = (int16_t)val;
+            if (store_ac) {
+                O->acc.x = O->acc.y; O->acc.y = O->acc.z; O->acc.z = O->acc.w;
+                O->acc.w = ((uint32_t)val << 16) | zr;
+                O->epos++;
+                if ((O->epos & 3) == 0) {
+                    if (O->epos - O->epos0 >= 4) *reinterpret_cast<uint4 *>(O->ent + O->epos - 4) = O->acc;
+                    else {                                   // lane started inside this group of four
+                        const uint32_t n = O->epos - O->epos0;
+                        O->ent[O->epos - 1] = O->acc.w;
+                        if (n >= 2) O->ent[O->epos - 2] = O->acc.z;
+                        if (n >= 3) O->ent[O->epos - 3] = O->acc.y;
+                    }
+                }
+            }
+            if (done) O->du_end[D] = O->epos;
         }
-        const bool done = znew >= 64;
         z = done ? 0u : znew;
         c = done ? ((c + 1 == dus) ? 0u : c + 1) : c;
-        ndu += done;
+        ndu += (done ? 1u : 0u) + (store_ac ? 0x10000u : 0u);
         if (MODE == MODE_WRITE) D += done;
+        else D += 1;                                       // diagnostics: symbols decoded
+    }
+    if (MODE == MODE_WRITE) {
+        // entries of the last, incomplete group of four
+        const uint32_t mine = O->epos - O->epos0, pend = (O->epos & 3) < mine ? (O->epos & 3) : mine;
+        if (pend >= 1) O->ent[O->epos - 1] = O->acc.w;
+        if (pend >= 2) O->ent[O->epos - 2] = O->acc.z;
+        if (pend >= 3) O->ent[O->epos - 3] = O->acc.y;
     }
     if (MODE != MODE_WRITE) {
         // checkpoints (re)written in this pass hold "units so far"; make them "units still to come"
@@ -328,13 +365,25 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_sync(PjdDevBatch 
     const PjdDevHuffWg wg = B.hwgs[w];
     const PjdDevImage &im = B.images[wg.image];
     LaneGeom g; uint32_t tpacked; ChkCtx K;
+    const uint64_t tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
     wave_setup(B, wg, im, g, tpacked, K);
+    const uint64_t tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
     // round 0: every lane from the start of its own subsequence (the true state at a segment start)
     uint32_t p = g.start_bit, c = 0, z = 0, ndu = 0, err = 0, D = 0;
     if (g.valid) decode_span<MODE_SPEC>(pjd_huff_lds, tpacked, im.n_luma, im.dus_per_mcu, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
+    const uint64_t tc2 = __builtin_amdgcn_s_memtime(), tr2 = __builtin_amdgcn_s_memrealtime();
     WaveState S = { p + g.base_bit, (c << 8) | z, ndu };
     const uint64_t entry0 = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);       // lane 0: the assumed entry
     const bool ok = wave_rounds(im, g, tpacked, K, S, g.valid ? 1u : 0u, B.stats, 0);
+    const uint64_t tc3 = __builtin_amdgcn_s_memtime(), tr3 = __builtin_amdgcn_s_memrealtime();
+    {
+        uint32_t mx = D;
+        for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+        if (t == 0 && B.stats) {
+            atomicAdd(B.stats + 4, tc1 - tc0); atomicAdd(B.stats + 5, tc2 - tc1); atomicAdd(B.stats + 6, tc3 - tc2); atomicAdd(B.stats + 7, (unsigned long long)mx);
+            atomicAdd(B.stats + 8, tr1 - tr0); atomicAdd(B.stats + 9, tr2 - tr1); atomicAdd(B.stats + 10, tr3 - tr2);
+        }
+    }
     if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
     if (g.owned) {
         B.sub_exit[g.q] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
@@ -419,34 +468,39 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_fix(PjdDevBatch B
         if (t == 0) exit1[w] = B.wg_exit[w];
         if (t >= 1 && t - 1 < wg.n_sub) my_cnt = B.sub_cnt[wg.first_sub + t - 1];
     }
-    // per-wave aggregate of data-unit counts: (absolute index after the last owned lane if a segment
-    // starts inside, else the number of units completed), head flag
-    uint32_t v = 0, f = 0;
+    // per-wave aggregates: data units (absolute index after the last owned lane if a segment starts
+    // inside, else the number of units completed; head flag) and coefficient entries (plain sum)
+    uint32_t v = 0, f = 0, e = 0;
     if (t >= 1 && t - 1 < wg.n_sub) {
         const uint32_t sg = B.subs[wg.first_sub + t - 1].seg;
-        v = my_cnt;
+        v = my_cnt & 0xffffu;
+        e = my_cnt >> 16;
         if (sg >> 31) { f = 1; v += B.segs[sg & 0x7fffffffu].first_du; }
     }
     wave_seg_scan(v, f);
-    if (t == PJD_HUFF_THREADS - 1) { B.wg_agg[2 * w] = v; B.wg_agg[2 * w + 1] = f; }
+    for (int off = 32; off; off >>= 1) e += __shfl_xor(e, off);
+    if (t == PJD_HUFF_THREADS - 1) { B.wg_agg[2 * w] = v; B.wg_agg[2 * w + 1] = f; B.wg_eagg[w] = e; }
 }
 
 __global__ __launch_bounds__(64) void pjd_k_huff_carry(PjdDevBatch B)
 {
     const PjdDevImage &im = B.images[blockIdx.x];
     const uint32_t lane = threadIdx.x, n = im.n_hwg;
-    uint32_t carry = 0;
+    uint32_t carry = 0, ecarry = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t j = base + lane;
-        uint32_t v = 0, f = 0;
-        if (j < n) { v = B.wg_agg[2 * (im.hwg_base + j)]; f = B.wg_agg[2 * (im.hwg_base + j) + 1]; }
+        uint32_t v = 0, f = 0, e = 0;
+        if (j < n) { v = B.wg_agg[2 * (im.hwg_base + j)]; f = B.wg_agg[2 * (im.hwg_base + j) + 1]; e = B.wg_eagg[im.hwg_base + j]; }
         wave_seg_scan(v, f);
         const uint32_t pv = __shfl_up(v, 1), pf = __shfl_up(f, 1);
         uint32_t in = carry;
         if (lane > 0) in = pf ? pv : carry + pv;
-        if (j < n) B.wg_du_in[im.hwg_base + j] = in;
+        uint32_t es = e;                                        // inclusive scan of entries
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(es, off); if ((int)lane >= off) es += o; }
+        if (j < n) { B.wg_du_in[im.hwg_base + j] = in; B.wg_ent_in[im.hwg_base + j] = ecarry + es - e; }
         const uint32_t lv = __shfl(v, 63), lf = __shfl(f, 63);
         carry = lf ? lv : carry + lv;
+        ecarry += __shfl(es, 63);
     }
 }
 
@@ -464,16 +518,19 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
     // the entry this wave was synchronised with must be what its predecessor finally produced
     if (t == 0 && !first_is_head && B.wg_entry[w] != B.wg_exit[B.n_hwg + w - 1]) flag = 1;
 
-    // absolute data-unit index at the entry of every owned lane
-    uint32_t cnt = 0, v = 0, f = 0, seg_first_du = 0, seg_n_du = 0;
+    // absolute data-unit index and entry index at the entry of every owned lane
+    uint32_t cnt = 0, ecnt = 0, v = 0, f = 0, seg_first_du = 0, seg_n_du = 0;
     if (g.owned) {
-        cnt = B.sub_cnt[g.q];
+        const uint32_t packed = B.sub_cnt[g.q];
+        cnt = packed & 0xffffu; ecnt = packed >> 16;
         const PjdDevSegment sg = B.segs[g.seg];
         seg_first_du = sg.first_du; seg_n_du = sg.n_du;
         v = cnt;
         if (g.seg_first) { f = 1; v += seg_first_du; }
     }
     wave_seg_scan(v, f);
+    uint32_t es = ecnt;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(es, off); if ((int)t >= off) es += o; }
     if (g.owned) {
         const uint32_t D_out = f ? v : B.wg_du_in[w] + v;
         uint32_t D = D_out - cnt;
@@ -486,9 +543,15 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
             if (D_in < D_end && (D_in % dus) != c) flag = 1;          // phase must agree with the count
         }
         uint32_t ndu = 0, err = 0;
-        int16_t *coef_img = B.coef + im.du_base * 64;
+        OutCtx O;
+        O.ent = B.ent + im.ent_base;
+        O.du_end = B.du_end + im.du_base;
+        O.dcv = B.dcv + im.du_base;
+        O.epos = O.epos0 = B.wg_ent_in[w] + es - ecnt;
+        O.acc = make_uint4(0, 0, 0, 0);
+        if (g.seg_first) B.seg_ent[g.seg] = O.epos;
         if (D_in < D_end) {
-            decode_span<MODE_WRITE>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, coef_img, D, D_end);
+            decode_span<MODE_WRITE>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, &O, D, D_end);
             if (err) flag = 1;
             if (D == D_end) {
                 // this lane completed the segment: the reference's BitReader must be able to reach
@@ -497,9 +560,10 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
                 const bool has_next = g.seg + 1 < im.seg_base + im.n_seg;
                 if (has_next && ((p + 7) & ~7u) != g.seg_end_bit) flag = 1;
             } else {
-                // stopped at the subsequence end: must reproduce the synchronised exit state
+                // stopped at the subsequence end: must reproduce the synchronised exit state and counts
                 const uint64_t e = B.sub_exit[g.q];
                 if ((uint32_t)e - g.base_bit != p || ((uint32_t)(e >> 32) & 255) != c || ((uint32_t)(e >> 40) & 255) != z) flag = 1;
+                if (ndu != B.sub_cnt[g.q]) flag = 1;
                 if (g.seg_last) flag = 1;                              // data ended before all units were decoded
             }
         }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void pjd_k_huff_sequential(PjdDevBatch B, const
     const PjdDevImage &im = B.images[ii];
     const PjdDevHuffRaw *tabs = B.raw_tables + (size_t)ii * PJD_MAX_TABLES;
     SeqReader r = { B.ecs + im.ecs_off, im.ecs_len * 8u, 0u };
-    int16_t *coef = B.coef + im.du_base * 64;
+    int16_t *coef = B.coef + im.dense_base * 64;
     const uint32_t RI = im.restart_interval, Wr = im.ref_mcu_w_real;
     const bool std_rule = (im.flags & PJD_IF_STANDARD_RESTART) != 0;
     int pred[3] = {0, 0, 0};

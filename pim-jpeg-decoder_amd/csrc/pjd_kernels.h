@@ -16,7 +16,11 @@ struct PjdDevBatch {
     const PjdDevHuffWg *hwgs;
     const PjdDevIdctWg *iwgs;
     const uint8_t *ecs;
-    int16_t *coef;                       // n_du * 64, zigzag-slot order
+    int16_t *coef;                       // DENSE scratch (exact-kernel path): dense_du * 64 int16, zigzag-slot order
+    uint32_t *ent;                       // coefficient entries of the parallel path: (value << 16) | slot, AC only
+    uint32_t *du_end;                    // per data unit: entry index (image-relative) just past its last entry
+    uint32_t *seg_ent;                   // per restart segment: entry index (image-relative) of its first entry
+    int16_t *dcv;                        // per data unit: DC difference, integrated in place by pjd_k_dc_*
     uint8_t *out;
     int32_t *status;                     // per image
     // Huffman synchronisation scratch
@@ -27,6 +31,8 @@ struct PjdDevBatch {
     uint64_t *wg_exit;                   // [2][n_hwg]: exit state of its last owned subsequence, generation 0/1
     uint32_t *wg_agg;                    // per Huffman workgroup: {value, has_head}
     uint32_t *wg_du_in;                  // per Huffman workgroup: absolute data-unit index at its entry
+    uint32_t *wg_eagg;                   // per Huffman workgroup: entries its subsequences produce
+    uint32_t *wg_ent_in;                 // per Huffman workgroup: entry index (image-relative) at its entry
     // DC prediction scratch
     uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
     uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
@@ -39,7 +45,8 @@ struct PjdDevBatch {
 
 // ---- back end (pjd_k_backend.hip) ------------------------------------------------
 void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus);
-void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg);
+void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg);          // dense input (exact path)
+void pjd_launch_idct_colour_sparse(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg);   // entry-stream input
 void pjd_launch_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernels: local scan + carry
 // ---- entropy decode (pjd_k_huffman.hip) -----------------------------------------
 void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, uint32_t n);

@@ -64,7 +64,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     }
     const uint32_t SB = P.sub_bytes;
 
-    uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0;
+    uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0, ent_base = 0, dense_seq = 0, dense_fb = 0;
     for (int i = 0; i < n; i++) {
         const pjd_image_desc &d = images[i];
         PjdDevImage &g = P.images[i];
@@ -218,9 +218,15 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             P.seq_images.push_back((uint32_t)i);
         }
 
-        // ---- coefficient scratch, DC scan blocks, IDCT workgroups, output
+        // ---- coefficient entries, per-unit arrays, DC scan blocks, IDCT workgroups, output
+        g.image_index = (uint32_t)i;
         g.du_base = du_base;
         du_base += g.n_du;
+        // an AC entry costs at least 2 bits of stream (1-bit code + 1 value bit): capacity bound
+        g.ent_base = ent_base;
+        if (!sequential) ent_base = align_up(ent_base + h.ecs_copy_len * 4 + g.n_du + 8, 4);   // >= 2 bits per entry, +1 size-0 entry per unit
+        if (sequential) { g.dense_base = dense_seq; dense_seq += g.n_du; }
+        else if (g.n_du > dense_fb) dense_fb = g.n_du;
         g.dcblk_base = (uint32_t)dcblk;
         g.n_dcblk = (g.n_mcu + PJD_DC_BLOCK - 1) / PJD_DC_BLOCK;
         dcblk += g.n_dcblk;
@@ -231,7 +237,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             w.first_mcu = m;
             w.n_mcu = (g.last_mcu - m < per_wg) ? g.last_mcu - m : per_wg;
             w.pad_ = 0;
-            P.iwgs.push_back(w);
+            (sequential ? P.iwgs_dense : P.iwgs).push_back(w);
         }
         h.out_bytes = pjd_output_size(d.width, d.height, out_format);
         g.out_off = out_off;
@@ -243,6 +249,9 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     }
     P.ecs_buf_bytes = align_up(ecs_off + 256, 256);
     P.n_du = du_base;
+    P.n_ent = ent_base + 16;
+    for (int i = 0; i < n; i++) if (!P.host[i].sequential) P.images[i].dense_base = dense_seq;   // shared fallback scratch
+    P.dense_du = dense_seq + dense_fb;
     P.out_buf_bytes = align_up(out_off, 256);
     P.n_dcblk = dcblk;
     if (P.ecs_buf_bytes >= (1ull << 40)) { err = "batch bitstream too large"; return PJD_E_ARG; }

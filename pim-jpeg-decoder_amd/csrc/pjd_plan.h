@@ -23,11 +23,14 @@ struct PjdPlan {
     std::vector<PjdDevSegment> segs;
     std::vector<PjdDevSub> subs;
     std::vector<PjdDevHuffWg> hwgs;
-    std::vector<PjdDevIdctWg> iwgs;
+    std::vector<PjdDevIdctWg> iwgs;        // images decoded by the parallel path (sparse back end)
+    std::vector<PjdDevIdctWg> iwgs_dense;  // images routed to the exact kernel up front (dense back end)
     std::vector<uint32_t> seq_images;      // indices of `sequential` images
     std::vector<uint32_t> fast_images;     // the others
     uint64_t ecs_buf_bytes = 0;            // size of the packed bitstream buffer (incl. padding)
-    uint64_t n_du = 0;                     // data units in the coefficient buffer
+    uint64_t n_du = 0;                     // data units in the batch
+    uint64_t n_ent = 0;                    // capacity of the coefficient-entry stream (entries)
+    uint64_t dense_du = 0;                 // data units of the dense scratch (exact-kernel images + one fallback image)
     uint64_t out_buf_bytes = 0;
     uint64_t n_dcblk = 0;
     uint64_t pixels = 0, ecs_bytes = 0, out_bytes = 0;
