@@ -187,9 +187,13 @@ __global__ __launch_bounds__(64) void pjd_k_dc_carry(PjdDevBatch B)
 
 // Row pass, column pass, chroma upsample + colour + raster store for the data units staged in `tile`
 // (natural order, dequantised).  Shared by the sparse and the dense front ends.
-__device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE], const PjdDevBatch &B, const PjdDevImage &im,
-                                                   const PjdDevIdctWg &wg, uint32_t tid)
+__device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE], uint32_t *mcu_xy, const PjdDevBatch &B,
+                                                   const PjdDevImage &im, const PjdDevIdctWg &wg, uint32_t tid)
 {
+    if (tid < wg.n_mcu) {                                   // grid position of each MCU: the only divisions
+        const uint32_t m = wg.first_mcu + tid, my = m / im.mcux;
+        mcu_xy[tid] = (my << 16) | (m - my * im.mcux);
+    }
     const uint32_t dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp, hs = im.hs, vs = im.vs;
     const uint32_t n_du = wg.n_mcu * dus;
     __syncthreads();
@@ -217,7 +221,6 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
 
     // ---- chroma upsample (nearest neighbour, decoder_dpu.c:370), colour, raster store --------
     const uint32_t mw = 8 * hs, mh = 8 * vs;
-    const uint32_t n_px = wg.n_mcu * mw * mh;
     const bool bmp = (im.flags & PJD_IF_BMP) != 0;
     uint8_t *out = B.out + im.out_off;
     if (bmp && wg.first_mcu == 0 && tid < 26) {
@@ -236,27 +239,31 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
         }
         out[tid] = hb;
     }
-    for (uint32_t i = tid; i < n_px; i += PJD_IDCT_THREADS) {
-        const uint32_t px = i % mw;
-        const uint32_t t = i / mw;
-        const uint32_t ml = t % wg.n_mcu, py = t / wg.n_mcu;
-        const uint32_t m = wg.first_mcu + ml;
-        const uint32_t my = m / im.mcux, mx = m - my * im.mcux;
-        const uint32_t X = mx * mw + px, Y = my * mh + py;
-        if (X >= im.width || Y >= im.height) continue;
-        const uint32_t d0 = ml * dus;
-        const int yv = tile[d0 + (py >> 3) * hs + (px >> 3)][(py & 7) * 8 + (px & 7)];
-        const uint32_t q = (py / vs) * 8 + (px / hs);
-        const int cb = nc > 1 ? tile[d0 + nl][q] : 0;
-        const int cr = nc > 2 ? tile[d0 + nl + 1][q] : 0;
-        int r, g, b;
-        pjd_ycc_to_rgb(yv, cb, cr, r, g, b);
-        if (bmp) {
-            uint8_t *o = out + 26 + (size_t)(im.height - 1 - Y) * im.out_stride + X * 3;
-            o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
-        } else {
-            uint8_t *o = out + (size_t)Y * im.out_stride + X * 3;
-            o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+    // pixel -> thread map without runtime divisions: mw is 8 or 16, so (MCU, column) come from shifts;
+    // rows are an outer loop; the MCU's grid position was tabulated once per workgroup (mcu_xy)
+    const uint32_t mw_log = hs == 2 ? 4u : 3u, hs_log = hs - 1, vs_log = vs - 1;
+    const uint32_t row_items = wg.n_mcu << mw_log;
+    for (uint32_t py = 0; py < mh; py++) {
+        const uint32_t cy = py >> vs_log, lrow = (py >> 3) * hs;
+        for (uint32_t i = tid; i < row_items; i += PJD_IDCT_THREADS) {
+            const uint32_t ml = i >> mw_log, px = i & (mw - 1);
+            const uint32_t xy = mcu_xy[ml];
+            const uint32_t X = (xy & 0xffffu) * mw + px, Y = (xy >> 16) * mh + py;
+            if (X >= im.width || Y >= im.height) continue;
+            const uint32_t d0 = ml * dus;
+            const int yv = tile[d0 + lrow + (px >> 3)][(py & 7) * 8 + (px & 7)];
+            const uint32_t q = cy * 8 + (px >> hs_log);
+            const int cb = nc > 1 ? tile[d0 + nl][q] : 0;
+            const int cr = nc > 2 ? tile[d0 + nl + 1][q] : 0;
+            int r, g, b;
+            pjd_ycc_to_rgb(yv, cb, cr, r, g, b);
+            if (bmp) {
+                uint8_t *o = out + 26 + (size_t)(im.height - 1 - Y) * im.out_stride + X * 3;
+                o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
+            } else {
+                uint8_t *o = out + (size_t)Y * im.out_stride + X * 3;
+                o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+            }
         }
     }
 }
@@ -268,11 +275,12 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint16_t qs[3][64];
+    __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
 
     const PjdDevIdctWg wg = wgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
     const uint32_t tid = threadIdx.x;
-    const uint32_t dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp, hs = im.hs, vs = im.vs;
+    const uint32_t dus = im.dus_per_mcu, nl = im.n_luma;
     const uint32_t n_du = wg.n_mcu * dus;
     const uint32_t RI = im.restart_interval;
 
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
         }
     }
     __syncthreads();
-    pjd_tile_to_pixels(tile, B, im, wg, tid);
+    pjd_tile_to_pixels(tile, mcu_xy, B, im, wg, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -328,8 +336,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint16_t qs[3][64];
-    __shared__ uint32_t e_lo[PJD_IDCT_MAX_DU], e_hi[PJD_IDCT_MAX_DU], s52[PJD_IDCT_MAX_DU];
-    __shared__ uint8_t zzs[64];
+    __shared__ uint32_t e_lo[PJD_IDCT_MAX_DU], e_hi[PJD_IDCT_MAX_DU], s52[PJD_IDCT_MAX_DU], mcu_xy[PJD_IDCT_MAX_DU];
+    __shared__ uint8_t zzs[64], du_comp[PJD_IDCT_MAX_DU], du_ml[PJD_IDCT_MAX_DU];
 
     const PjdDevIdctWg wg = wgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
@@ -355,6 +363,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
         e_lo[tid] = seg_first ? B.seg_ent[seg] : de[d - 1];
         e_hi[tid] = de[d];
         s52[tid] = 0;
+        du_comp[tid] = (uint8_t)(k < nl ? 0 : k - nl + 1);
+        du_ml[tid] = (uint8_t)(tid / dus);
     }
     __syncthreads();
 
@@ -362,13 +372,12 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
     const int16_t *dcv = B.dcv + im.du_base + d0;
     for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
         const uint32_t du = i >> 3, r = i & 7;
-        const uint32_t ml = du / dus, k = du - ml * dus;
-        const uint32_t comp = k < nl ? 0 : k - nl + 1;
+        const uint32_t comp = du_comp[du];
         const uint16_t *q = qs[comp];
         int16_t *t = tile[du];
         if (r == 0) {
             int dc = dcv[du];
-            const uint32_t m = wg.first_mcu + ml;
+            const uint32_t m = wg.first_mcu + du_ml[du];
             const uint32_t blk = m / PJD_DC_BLOCK;
             const uint32_t hm = RI ? (m / RI) * RI : 0;          // last restart point at or before m
             if (hm < blk * PJD_DC_BLOCK) {                        // none inside this scan block: carry applies
@@ -387,13 +396,10 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
         }
     }
     __syncthreads();
-    if (tid < n_du && s52[tid]) {
-        const uint32_t ml = tid / dus, k = tid - ml * dus;
-        const uint32_t comp = k < nl ? 0 : k - nl + 1;
-        tile[tid][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[tid] & 0xffffu), qs[comp][38]);
-    }
+    if (tid < n_du && s52[tid])
+        tile[tid][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[tid] & 0xffffu), qs[du_comp[tid]][38]);
     __syncthreads();
-    pjd_tile_to_pixels(tile, B, im, wg, tid);
+    pjd_tile_to_pixels(tile, mcu_xy, B, im, wg, tid);
 }
 
 void pjd_launch_idct_colour_sparse(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)
