@@ -218,3 +218,80 @@ def test_sharded_single_image_union_matches_oracle(ctx, port, name, world):
             y0, x0 = (m // mcux) * 8, (m % mcux) * 8
             got[y0:y0 + 8, x0:x0 + 8] = outs[0][y0:y0 + 8, x0:x0 + 8]
     assert np.array_equal(got, want)
+
+
+# ---- BASELINE-size cases (synthetic, seeded; tools/synth.py) ---------------------------------------
+def _synth():
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    return synth
+
+
+def test_config2_single_4k_matches_oracle(ctx, port):
+    """BASELINE config 2: one 3840x2160 4:2:0 JPEG, with and without restart markers (bit-exact)."""
+    import pjd_amd
+    synth = _synth()
+    for rst in (False, True):
+        data = synth.cfg2_single_4k(seed=2, restart_rows=rst)
+        s = pjd_amd.Scanned(data)
+        assert s.valid
+        if rst:
+            s.desc.flags = pjd_amd.F_STANDARD_RESTART      # 4:2:0 + DRI: the reference's own rule garbles it
+        want = port.decode(data)
+        with ctx.batch([s.desc]) as b:
+            b.upload(); b.decode()
+            outs, st = b.download()
+            info = b.info()
+        assert st == [0] and info["n_sequential"] == 0 and info["n_fallback"] == 0
+        if not rst:
+            assert np.array_equal(outs[0], want["rgb"])
+        else:
+            # oracle = reference rule (garbled); the standard-rule decode must equal the no-DRI picture's decode
+            # of the same source image up to the encoder's identical quantisation: compare with the port on the
+            # no-restart encoding of the same picture
+            plain = port.decode(synth.cfg2_single_4k(seed=2, restart_rows=False))
+            assert np.array_equal(outs[0], plain["rgb"])
+
+
+def test_config5_tile_444_restart_rows_matches_oracle(ctx, port):
+    """BASELINE config 5 shape at reduced size: 4:4:4, one restart interval per MCU row."""
+    import pjd_amd
+    synth = _synth()
+    data = synth.cfg5_tile(2048, seed=5)
+    s = pjd_amd.Scanned(data)
+    want = port.decode(data)
+    assert want["huff_rc"] == 0
+    with ctx.batch([s.desc]) as b:
+        b.upload(); b.decode()
+        outs, st = b.download()
+        info = b.info()
+    assert st == [0] and info["n_sequential"] == 0 and info["n_fallback"] == 0
+    assert np.array_equal(outs[0], want["rgb"])
+
+
+def test_config3_batch_properties(ctx, port):
+    """BASELINE config 3 at full size (1024 images): per-image results equal single-image decodes
+    (batch independence), decoding twice is idempotent, a sample equals the oracle."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = synth.cfg3_imagenet_like(1024, seed=3)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    with ctx.batch([s.desc for s in scanned]) as b:
+        b.upload(); b.decode()
+        outs, st = b.download()
+        info = b.info()
+        b.decode()
+        outs2, st2 = b.download()
+    assert st == [0] * 1024 and st2 == st
+    assert info["n_fallback"] == 0 and info["n_sequential"] == 0
+    h1 = hashlib.sha256(b"".join(o.tobytes() for o in outs)).hexdigest()
+    h2 = hashlib.sha256(b"".join(o.tobytes() for o in outs2)).hexdigest()
+    assert h1 == h2
+    for i in (0, 1, 511, 1023):
+        assert np.array_equal(outs[i], port.decode(jpegs[i])["rgb"]), i
+    # batch independence: images decoded alone give the same bytes
+    for i in (7, 300, 900):
+        alone, _ = ctx.decode([scanned[i].desc])
+        assert np.array_equal(alone[0], outs[i])
