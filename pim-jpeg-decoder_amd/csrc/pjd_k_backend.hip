@@ -239,30 +239,65 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
         }
         out[tid] = hb;
     }
-    // pixel -> thread map without runtime divisions: mw is 8 or 16, so (MCU, column) come from shifts;
-    // rows are an outer loop; the MCU's grid position was tabulated once per workgroup (mcu_xy)
-    const uint32_t mw_log = hs == 2 ? 4u : 3u, hs_log = hs - 1, vs_log = vs - 1;
-    const uint32_t row_items = wg.n_mcu << mw_log;
-    for (uint32_t py = 0; py < mh; py++) {
-        const uint32_t cy = py >> vs_log, lrow = (py >> 3) * hs;
-        for (uint32_t i = tid; i < row_items; i += PJD_IDCT_THREADS) {
-            const uint32_t ml = i >> mw_log, px = i & (mw - 1);
+    // Colour + store: a thread takes FOUR horizontally adjacent pixels (12 output bytes, written as one
+    // 12-byte store -- gfx950 global stores need no alignment), thread rows of 64 items sweep `mh` picture
+    // rows four at a time.  No runtime divisions: mw is 8 or 16, the MCU grid position was tabulated once.
+    const uint32_t q_log = hs == 2 ? 2u : 1u;                  // log2(mw / 4): items per MCU row
+    const uint32_t hs_log = hs - 1, vs_log = vs - 1;
+    const uint32_t items = wg.n_mcu << q_log;
+    struct __attribute__((packed)) Px12 { uint32_t a, b, c; };
+    for (uint32_t py = tid >> 6; py < mh; py += PJD_IDCT_THREADS / 64) {
+        const uint32_t cy = py >> vs_log, lrow = (py >> 3) * hs, yoff = (py & 7) * 8;
+        for (uint32_t it = tid & 63; it < items; it += 64) {
+            const uint32_t ml = it >> q_log, px0 = (it & ((1u << q_log) - 1)) * 4;
             const uint32_t xy = mcu_xy[ml];
-            const uint32_t X = (xy & 0xffffu) * mw + px, Y = (xy >> 16) * mh + py;
+            const uint32_t X = (xy & 0xffffu) * mw + px0, Y = (xy >> 16) * mh + py;
             if (X >= im.width || Y >= im.height) continue;
             const uint32_t d0 = ml * dus;
-            const int yv = tile[d0 + lrow + (px >> 3)][(py & 7) * 8 + (px & 7)];
-            const uint32_t q = cy * 8 + (px >> hs_log);
-            const int cb = nc > 1 ? tile[d0 + nl][q] : 0;
-            const int cr = nc > 2 ? tile[d0 + nl + 1][q] : 0;
-            int r, g, b;
-            pjd_ycc_to_rgb(yv, cb, cr, r, g, b);
-            if (bmp) {
-                uint8_t *o = out + 26 + (size_t)(im.height - 1 - Y) * im.out_stride + X * 3;
-                o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
-            } else {
-                uint8_t *o = out + (size_t)Y * im.out_stride + X * 3;
-                o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+            const int16_t *yp = &tile[d0 + lrow + (px0 >> 3)][yoff + (px0 & 7)];
+            const uint2 yraw = *reinterpret_cast<const uint2 *>(yp);               // 4 luma samples
+            const int y0 = (int16_t)(yraw.x & 0xffff), y1 = (int16_t)(yraw.x >> 16), y2 = (int16_t)(yraw.y & 0xffff), y3 = (int16_t)(yraw.y >> 16);
+            int cb[4] = {0, 0, 0, 0}, cr[4] = {0, 0, 0, 0};      // constant indices only: stay in registers
+            const uint32_t q = cy * 8 + (px0 >> hs_log);
+            if (nc > 1) {
+                if (hs == 2) {                                                       // 2 chroma samples cover 4 pixels
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(&tile[d0 + nl][q]);
+                    cb[0] = cb[1] = (int16_t)(w & 0xffff); cb[2] = cb[3] = (int16_t)(w >> 16);
+                } else {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(&tile[d0 + nl][q]);
+                    cb[0] = (int16_t)(w.x & 0xffff); cb[1] = (int16_t)(w.x >> 16); cb[2] = (int16_t)(w.y & 0xffff); cb[3] = (int16_t)(w.y >> 16);
+                }
+            }
+            if (nc > 2) {
+                if (hs == 2) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(&tile[d0 + nl + 1][q]);
+                    cr[0] = cr[1] = (int16_t)(w & 0xffff); cr[2] = cr[3] = (int16_t)(w >> 16);
+                } else {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(&tile[d0 + nl + 1][q]);
+                    cr[0] = (int16_t)(w.x & 0xffff); cr[1] = (int16_t)(w.x >> 16); cr[2] = (int16_t)(w.y & 0xffff); cr[3] = (int16_t)(w.y >> 16);
+                }
+            }
+            // first / middle / last byte of each pixel: R,G,B -- or B,G,R for the BMP image
+            uint32_t f0, f1, f2, f3, g0, g1, g2, g3, l0, l1, l2, l3;
+            {
+                int rr, gg, bb;
+                pjd_ycc_to_rgb(y0, cb[0], cr[0], rr, gg, bb); f0 = bmp ? bb : rr; g0 = gg; l0 = bmp ? rr : bb;
+                pjd_ycc_to_rgb(y1, cb[1], cr[1], rr, gg, bb); f1 = bmp ? bb : rr; g1 = gg; l1 = bmp ? rr : bb;
+                pjd_ycc_to_rgb(y2, cb[2], cr[2], rr, gg, bb); f2 = bmp ? bb : rr; g2 = gg; l2 = bmp ? rr : bb;
+                pjd_ycc_to_rgb(y3, cb[3], cr[3], rr, gg, bb); f3 = bmp ? bb : rr; g3 = gg; l3 = bmp ? rr : bb;
+            }
+            uint8_t *o = bmp ? out + 26 + (size_t)(im.height - 1 - Y) * im.out_stride + X * 3
+                             : out + (size_t)Y * im.out_stride + X * 3;
+            if (X + 4 <= im.width) {
+                Px12 v;
+                v.a = f0 | (g0 << 8) | (l0 << 16) | (f1 << 24);
+                v.b = g1 | (l1 << 8) | (f2 << 16) | (g2 << 24);
+                v.c = l2 | (f3 << 8) | (g3 << 16) | (l3 << 24);
+                *reinterpret_cast<Px12 *>(o) = v;
+            } else {                                                             // right picture edge
+                o[0] = (uint8_t)f0; o[1] = (uint8_t)g0; o[2] = (uint8_t)l0;
+                if (X + 1 < im.width) { o[3] = (uint8_t)f1; o[4] = (uint8_t)g1; o[5] = (uint8_t)l1; }
+                if (X + 2 < im.width) { o[6] = (uint8_t)f2; o[7] = (uint8_t)g2; o[8] = (uint8_t)l2; }
             }
         }
     }
