@@ -124,6 +124,10 @@ def main():
     scanned = [pjd_amd.Scanned(j) for j in jpegs]
     t_scan = time.perf_counter() - t_scan
     assert all(s.valid for s in scanned)
+    if args.workload == "cfg2rst":
+        # 4:2:0 + DRI: the reference's own restart rule garbles such files; decode per ITU-T.81
+        for s in scanned:
+            s.desc.flags = pjd_amd.F_STANDARD_RESTART
 
     ctx = pjd_amd.Context(local_rank)          # raises if the HIP library / a gfx950 device is missing
     batch = ctx.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8)
@@ -182,6 +186,17 @@ def main():
         dom = max(ktimes, key=ktimes.get)
         alg_bytes = info["ecs_bytes"] + info["out_bytes"]            # ECS read once + RGB8 written once
         achieved = alg_bytes / (ktimes[dom] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel per launch, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE, both KiB); only valid for the workload it was collected on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if args.workload == "cfg3" and args.images == 1024:
+                for k, v in tj["per_kernel"].items():
+                    if dom in k:
+                        traffic = int((2 * (v.get("fetch_kib_raw") or 0) + (v.get("write_kib") or 0)) * 1024)
+        except Exception:
+            traffic = None
         line = {
             "metric": "MPixels/sec JPEG->RGB (bit-exact BMP)", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,7 +208,7 @@ def main():
                        "hip_graph": not args.no_graph,
                        "sync": {k: info[k] for k in ("n_huff_workgroups", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes")}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(ktimes[dom], 4)},
             "kernels_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_pipeline_ms": round(ktotal, 4),
