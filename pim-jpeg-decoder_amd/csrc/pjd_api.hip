@@ -207,7 +207,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->d_seq_list, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->d_fb_list, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->d_status_init, (size_t)n_images, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.luts, P.tables.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.luts, (size_t)P.lut_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.coef, P.dense_du * 64, tot));
     TRY_RC(dev_alloc(ctx, b->dev.ent, P.n_ent, tot));
     TRY_RC(dev_alloc(ctx, b->dev.du_end, P.n_du, tot));
@@ -234,8 +234,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     b->dev.n_images = (uint32_t)n_images; b->dev.n_hwg = (uint32_t)P.hwgs.size();
     b->dev.n_iwg = (uint32_t)P.iwgs.size(); b->dev.n_dcblk = (uint32_t)P.n_dcblk;
     b->dev.sub_bytes = P.sub_bytes;
-    b->dev.max_tables = 1;
-    for (const PjdDevImage &im : P.images) if (im.n_tables > b->dev.max_tables) b->dev.max_tables = im.n_tables;
+    b->dev.max_lut_bytes = P.max_lut_bytes;
     *out = b;
     return PJD_OK;
 }

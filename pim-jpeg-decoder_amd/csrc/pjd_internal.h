@@ -13,6 +13,8 @@
 #define PJD_HUFF_OWNED     63       // subsequences owned per workgroup (lane 0 = predecessor overlap)
 #define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into)
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
+#define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
+#define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one image in LDS; larger -> exact kernel
 #define PJD_MAX_TABLES     6        // distinct Huffman tables one image can reference (3 DC + 3 AC)
 #define PJD_SYNC_MAX_ITERS 24       // re-sync rounds per wave before giving up (-> exact fallback)
 #define PJD_DC_BLOCK       256      // MCUs per DC-prediction scan block
@@ -54,6 +56,13 @@ struct PjdDevImage {
     uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1
     uint8_t  n_tables;
     uint8_t  pad_[1];
+    // decode tables of this image inside PjdDevBatch::luts (layout: see "decode-ready tables" below)
+    uint32_t lut_off16;                // blob offset in 16-byte units
+    uint32_t lut_bytes;                // multiple of 16; 0 for images routed to the exact kernel
+    uint16_t l2_off[PJD_MAX_TABLES];   // second-level region of table k: first u16 index, relative to the image's blob
+    uint16_t l2_p0[PJD_MAX_TABLES];    // 10-bit prefixes [p0, p1) hold codes longer than PJD_LUT_BITS
+    uint16_t l2_p1[PJD_MAX_TABLES];
+    uint16_t pad2_[2];
 };
 
 // raw Huffman table as shipped by the host (reference HuffmanTable, jpeg.h:129-134)
@@ -63,16 +72,16 @@ struct PjdDevHuffRaw {
     uint8_t is_ac;
 };                                     // 180 bytes
 
-// decode-ready table, built on the device by pjd_k_build_tables
-struct PjdDevHuffLut {
-    uint16_t lut[1 << PJD_LUT_BITS];   // (code length << 8) | symbol ; 0 => longer than LUT_BITS or invalid
-    uint32_t lim[8];                   // lim[k] = left-aligned 16-bit upper bound of codes of length <= LUT_BITS+k (k=0..6), lim[7] pad
-    int32_t  base[17];                 // base[L] = offsets[L-1] - first_code[L]  (symbol index = base[L] + code)
-    uint8_t  symbols[164];
-    uint32_t irregular;                // 1 if the table is not a proper prefix code (over-subscribed): exact kernel only
-    uint32_t pad_;
-};                                     // 2048 + 32 + 68 + 164 + 8 = 2320 bytes
-#define PJD_LUT_STRUCT_BYTES 2320
+// decode-ready tables, built on the device by pjd_k_build_tables.  One blob per image:
+//   [table 0 L1][table 1 L1]...[table n-1 L1][second-level regions, 64 u16 per long prefix]
+// L1 is indexed by the next PJD_LUT_BITS bits.  Entry (u16):
+//   bit 15 = 0 : (length << 8) | symbol, length 1..10;  bit 14 set = no code starts with these bits
+//                (then length = 16, symbol = 0: what the reference's get_next_symbol consumes before failing)
+//   bit 15 = 1 : codes with this prefix are longer than 10 bits; bits 14..0 = u16 index (relative to the blob)
+//                of the prefix's 64-entry second-level table, indexed by the following 6 bits; entries there
+//                have the first form with length 11..16.
+// Canonical codes keep all long codes in one contiguous range of prefixes [p0, p1), so the second level
+// costs 128 bytes per long prefix (Annex K tables: 5 prefixes for an AC table, 0..1 for a DC table).
 
 struct PjdDevSegment {                 // one restart segment
     uint32_t byte_start;               // relative to the image's ecs

@@ -20,7 +20,8 @@
 //     not a whole subsequence.  Only a lane that crosses its whole subsequence unmerged hands a
 //     changed exit state on to its successor for the next round.
 //
-//   pjd_k_build_tables   raw (offsets, symbols) tables -> 10-bit first-level LUT + length limits
+//   pjd_k_build_tables   raw (offsets, symbols) tables -> two-level decode table: 10-bit first level, one
+//                        64-entry second-level table per 10-bit prefix that holds longer codes
 //                        (semantics of reference generate_codes / get_next_symbol,
 //                        reference src/jpeg_scanner.cpp:438-465)
 //   pjd_k_huff_sync      rounds as above; exit state and data-unit count per subsequence
@@ -41,63 +42,54 @@
 #include "pjd_device_common.h"
 #include "pjd_kernels.h"
 
-#define LUT_BYTES   PJD_LUT_STRUCT_BYTES
-#define OFF_LIM     (2 << PJD_LUT_BITS)          // byte offsets inside PjdDevHuffLut
-#define OFF_BASE    (OFF_LIM + 32)
-#define OFF_SYMS    (OFF_BASE + 68)
-#define OFF_IRR     (OFF_SYMS + 164)
-
-static_assert(sizeof(PjdDevHuffLut) == LUT_BYTES, "LUT struct layout");
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
-static_assert(PJD_LUT_BITS == 10, "lim[] covers lengths 10..16");
+static_assert(PJD_LUT_BITS == 10, "second level is indexed by the 6 bits after a 10-bit prefix");
+
+#define LUT_BAD     (0x4000u | (16u << 8))       // no code: consume 16 bits (as the reference's get_next_symbol), symbol 0
 
 // ---------------------------------------------------------------------------------------------
+// One block per (image, table slot): two-level decode table (layout: pjd_internal.h).
 __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
 {
     const uint32_t img = blockIdx.x / PJD_MAX_TABLES, slot = blockIdx.x % PJD_MAX_TABLES;
-    if (slot >= B.images[img].n_tables) return;
+    const PjdDevImage &im = B.images[img];
+    if (slot >= im.n_tables || im.lut_bytes == 0) return;
     const PjdDevHuffRaw &r = B.raw_tables[(size_t)img * PJD_MAX_TABLES + slot];
-    PjdDevHuffLut &o = B.luts[(size_t)img * PJD_MAX_TABLES + slot];
+    uint16_t *blob = reinterpret_cast<uint16_t *>(B.luts + (size_t)im.lut_off16 * 16);
+    uint16_t *L1 = blob + slot * (PJD_L1_BYTES / 2);
+    const uint32_t l2_off = im.l2_off[slot], p0 = im.l2_p0[slot], p1 = im.l2_p1[slot];
     __shared__ uint32_t first[17];
     __shared__ uint8_t offs[17];
-    __shared__ uint32_t irregular;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
-        uint32_t code = 0, irr = 0;              // reference generate_codes
+        uint32_t code = 0;                       // reference generate_codes (jpeg_scanner.cpp:438-448)
         first[0] = 0;
         for (int len = 1; len <= 16; len++) {
             first[len] = code;
-            const uint32_t cnt = (uint32_t)(r.offsets[len] - r.offsets[len - 1]);
-            if (code + cnt > (1u << len)) irr = 1;        // over-subscribed: not a prefix code
-            code = (code + cnt) << 1;
+            code = (code + (uint32_t)(r.offsets[len] - r.offsets[len - 1])) << 1;
         }
-        irregular = irr;
     }
     if (tid < 17) offs[tid] = r.offsets[tid];
     __syncthreads();
     for (uint32_t idx = tid; idx < (1u << PJD_LUT_BITS); idx += 256) {
-        uint16_t e = 0;
+        uint32_t e = (idx >= p0 && idx < p1) ? (0x8000u | (l2_off + (idx - p0) * 64)) : LUT_BAD;
         for (uint32_t len = 1; len <= PJD_LUT_BITS; len++) {     // shortest match wins, as the reference's scan
             const uint32_t c = idx >> (PJD_LUT_BITS - len);
             const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
-            if (c >= first[len] && d < cnt) { e = (uint16_t)((len << 8) | r.symbols[offs[len - 1] + d]); break; }
+            if (c >= first[len] && d < cnt) { e = (len << 8) | r.symbols[offs[len - 1] + d]; break; }
         }
-        o.lut[idx] = e;
+        L1[idx] = (uint16_t)e;
     }
-    // lim[k]: a 16-bit window w holds a code of length <= 10+k  <=>  w < lim[k]
-    if (tid < 8) {
-        const uint32_t len = PJD_LUT_BITS + tid;
-        uint32_t v = 0;
-        if (len <= 16) {
-            const uint32_t cnt = (uint32_t)offs[len] - offs[len - 1];
-            v = (first[len] + cnt) << (16 - len);
-            if (v > 65536u) v = 65536u;
+    for (uint32_t j = tid; j < (p1 - p0) * 64; j += 256) {
+        const uint32_t w16 = (p0 << 6) + j;
+        uint32_t e = LUT_BAD;
+        for (uint32_t len = PJD_LUT_BITS + 1; len <= 16; len++) {
+            const uint32_t c = w16 >> (16 - len);
+            const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
+            if (c >= first[len] && d < cnt) { e = (len << 8) | r.symbols[offs[len - 1] + d]; break; }
         }
-        o.lim[tid] = v;
+        blob[l2_off + j] = (uint16_t)e;
     }
-    if (tid >= 1 && tid < 17) o.base[tid] = (int32_t)offs[tid - 1] - (int32_t)first[tid];
-    if (tid == 0) { o.base[0] = 0; o.irregular = irregular; o.pad_ = 0; }
-    if (tid < 164) o.symbols[tid] = tid < 162 ? r.symbols[tid] : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -177,6 +169,12 @@ __device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacke
     // `ndu` is a packed counter: data units completed in the low 16 bits, AC entries produced in the
     // high 16 bits (both fit for a subsequence of <= 1024 bytes)
     if (p >= end_bit) return false;
+    // wave-uniform image constants: as scalars they are waited for HERE; left in vector registers their
+    // first use sits inside the loop and drags a vmcnt(0) -- i.e. a wait for the stream prefetch -- into
+    // every iteration
+    nl = __builtin_amdgcn_readfirstlane(nl);
+    dus = __builtin_amdgcn_readfirstlane(dus);
+    tpacked = __builtin_amdgcn_readfirstlane(tpacked);
     BitWin w;
     w.init(base16, p);
     uint32_t j = 1, next_chk = K.start_bit + K.chk_bits;
@@ -193,26 +191,13 @@ __device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacke
         const uint32_t pk = w.peek();
         const bool is_dc = (z == 0);
         const uint32_t comp = (c >= nl ? 1u : 0u) + (c > nl ? 1u : 0u);
-        const uint8_t *tab = tabs + ((tpacked >> (8 * comp + (is_dc ? 0u : 4u))) & 15u) * LUT_BYTES;
-        const uint32_t e = *reinterpret_cast<const uint16_t *>(tab + 2 * (pk >> (32 - PJD_LUT_BITS)));
-        uint32_t len = e >> 8, sym = e & 255;
-        if (__builtin_expect(len == 0, 0)) {
-            // code longer than the LUT (rare) or invalid: its length follows from comparing the 16-bit
-            // window with the per-length limits of the canonical code; the symbol index bases for all
-            // candidate lengths are fetched together with the limits, so only ONE dependent read remains
-            const uint32_t w16 = pk >> 16;
-            const uint4 la = *reinterpret_cast<const uint4 *>(tab + OFF_LIM);          // limits, lengths 10..13
-            const uint4 lb = *reinterpret_cast<const uint4 *>(tab + OFF_LIM + 16);     // limits, lengths 14..16
-            const int32_t *bp = reinterpret_cast<const int32_t *>(tab + OFF_BASE);
-            const int32_t b11 = bp[11], b12 = bp[12], b13 = bp[13], b14 = bp[14], b15 = bp[15], b16 = bp[16];
-            len = PJD_LUT_BITS + 1 + (w16 >= la.y) + (w16 >= la.z) + (w16 >= la.w) + (w16 >= lb.x) + (w16 >= lb.y);
-            const int32_t bs = len == 11 ? b11 : len == 12 ? b12 : len == 13 ? b13 : len == 14 ? b14 : len == 15 ? b15 : b16;
-            const bool bad = w16 >= lb.z;
-            const uint32_t idx = bad ? 0u : (uint32_t)(bs + (int32_t)(w16 >> (16 - len)));
-            sym = bad ? 0u : tab[OFF_SYMS + (idx < 162u ? idx : 0u)];
-            len = bad ? 16u : len;
-            err |= bad;
-        }
+        const uint32_t slot = (tpacked >> (8 * comp + (is_dc ? 0u : 4u))) & 15u;
+        uint32_t e = *reinterpret_cast<const uint16_t *>(tabs + slot * PJD_L1_BYTES + 2 * (pk >> (32 - PJD_LUT_BITS)));
+        // code longer than 10 bits: one more read, in the 64-entry table of this 10-bit prefix
+        if (__builtin_expect((e & 0x8000u) != 0, 0))
+            e = *reinterpret_cast<const uint16_t *>(tabs + 2 * ((e & 0x7fffu) + ((pk >> 16) & 63u)));
+        const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+        err |= (e >> 14) & 1u;
         const uint32_t size = sym & 15, run = sym >> 4;
         const uint32_t used = len + size;
         w.drop(used);
@@ -311,18 +296,22 @@ __device__ __forceinline__ void wave_setup(const PjdDevBatch &B, const PjdDevHuf
     tpacked = 0;
     for (int cc = 0; cc < 3; cc++)
         tpacked |= ((uint32_t)im.tbl_slot[cc][0] << (8 * cc)) | ((uint32_t)im.tbl_slot[cc][1] << (8 * cc + 4));
-    // tables -> LDS (16 B per lane per step)
-    const uint32_t n16 = im.n_tables * (LUT_BYTES / 16);
-    const uint4 *tsrc = reinterpret_cast<const uint4 *>(B.luts + (size_t)wg.image * PJD_MAX_TABLES);
+    // tables -> LDS (16 B per lane per step, 4 loads in flight per lane)
+    const uint32_t n16 = im.lut_bytes / 16;
+    const uint4 *tsrc = reinterpret_cast<const uint4 *>(B.luts) + im.lut_off16;
     uint4 *tdst = reinterpret_cast<uint4 *>(pjd_huff_lds);
-    for (uint32_t i0 = 0; i0 < n16; i0 += 4 * PJD_HUFF_THREADS) {      // 4 loads in flight per lane
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * PJD_HUFF_THREADS + t; if (i < n16) v[u] = tsrc[i]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * PJD_HUFF_THREADS + t; if (i < n16) tdst[i] = v[u]; }
+    for (uint32_t i0 = t; i0 < n16; i0 += 4 * PJD_HUFF_THREADS) {
+        const uint32_t i1 = i0 + PJD_HUFF_THREADS, i2 = i1 + PJD_HUFF_THREADS, i3 = i2 + PJD_HUFF_THREADS;
+        uint4 v0 = tsrc[i0], v1, v2, v3;
+        if (i1 < n16) v1 = tsrc[i1];
+        if (i2 < n16) v2 = tsrc[i2];
+        if (i3 < n16) v3 = tsrc[i3];
+        tdst[i0] = v0;
+        if (i1 < n16) tdst[i1] = v1;
+        if (i2 < n16) tdst[i2] = v2;
+        if (i3 < n16) tdst[i3] = v3;
     }
-    uint32_t *chk = reinterpret_cast<uint32_t *>(pjd_huff_lds + B.max_tables * LUT_BYTES);
+    uint32_t *chk = reinterpret_cast<uint32_t *>(pjd_huff_lds + B.max_lut_bytes);
     K.state = chk + t;
     K.rem = chk + PJD_NCHK * 64 + t;
     K.start_bit = g.start_bit;
@@ -399,10 +388,6 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_sync(PjdDevBatch 
     }
     if (t == 0) {
         B.wg_entry[w] = g.valid ? entry0 : ~0ull;
-        // an over-subscribed Huffman table cannot be decoded by length limits: exact kernel
-        uint32_t irr = 0;
-        for (uint32_t k = 0; k < im.n_tables; k++) irr |= *reinterpret_cast<const uint32_t *>(pjd_huff_lds + k * LUT_BYTES + OFF_IRR);
-        if (irr) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
     }
     if (t == wg.n_sub) B.wg_exit[w] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
 }
@@ -572,7 +557,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_tables * LUT_BYTES + 2 * PJD_NCHK * 64 * sizeof(uint32_t); }
+static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + 2 * PJD_NCHK * 64 * sizeof(uint32_t); }
 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 {

@@ -9,7 +9,7 @@
 struct PjdDevBatch {
     const PjdDevImage *images;
     const PjdDevHuffRaw *raw_tables;     // n_images * PJD_MAX_TABLES
-    PjdDevHuffLut *luts;                 // n_images * PJD_MAX_TABLES
+    uint8_t *luts;                       // decode tables, one blob per image (PjdDevImage::lut_off16)
     const uint16_t *qtab;                // n_images * 3 * 64
     const PjdDevSegment *segs;
     const PjdDevSub *subs;
@@ -40,7 +40,7 @@ struct PjdDevBatch {
     unsigned long long *stats;           // [8] diagnostics: 0 sync rounds, 1 lane-passes in sync, 2 fix rounds, 3 lane-passes in fix
     uint32_t n_images, n_hwg, n_iwg, n_dcblk;
     uint32_t sub_bytes;                  // Huffman subsequence size of this batch
-    uint32_t max_tables;                 // largest n_tables in the batch (sizes the dynamic LDS of the Huffman kernels)
+    uint32_t max_lut_bytes;              // largest PjdDevImage::lut_bytes in the batch (sizes the dynamic LDS of the Huffman kernels)
 };
 
 // ---- back end (pjd_k_backend.hip) ------------------------------------------------

@@ -64,7 +64,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     }
     const uint32_t SB = P.sub_bytes;
 
-    uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0, ent_base = 0, dense_seq = 0, dense_fb = 0;
+    uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0, ent_base = 0, dense_seq = 0, dense_fb = 0, lut_off = 0;
     for (int i = 0; i < n; i++) {
         const pjd_image_desc &d = images[i];
         PjdDevImage &g = P.images[i];
@@ -136,12 +136,35 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                 g.tbl_slot[c][a] = (uint8_t)s;
             }
         g.n_tables = (uint8_t)nt;
+        // decode-table layout (pjd_internal.h): first-level tables, then one 64-entry second-level table per
+        // 10-bit prefix that holds codes longer than 10 bits.  Over-subscribed tables (not a prefix code) and
+        // tables whose long codes need more LDS than PJD_LUT_LDS_MAX go to the exact kernel.
+        bool tables_parallel_ok = true;
+        uint32_t lut_bytes = (uint32_t)nt * PJD_L1_BYTES;
+        for (int k = 0; k < nt; k++) {
+            const PjdDevHuffRaw &r = P.tables[(size_t)i * PJD_MAX_TABLES + k];
+            uint32_t code = 0, end10 = 0;
+            for (int len = 1; len <= 16; len++) {            // reference generate_codes (jpeg_scanner.cpp:438-448)
+                const uint32_t cnt = (uint32_t)r.offsets[len] - r.offsets[len - 1];
+                if (code + cnt > (1u << len)) tables_parallel_ok = false;
+                if (len == PJD_LUT_BITS) end10 = code + cnt;
+                code = (code + cnt) << 1;
+            }
+            const uint32_t end16 = code >> 1;
+            uint32_t p0 = end10 < 1024 ? end10 : 1024, p1 = (end16 + 63) >> 6;
+            if (p1 > 1024) p1 = 1024;
+            if (p1 < p0 || !tables_parallel_ok) p1 = p0;
+            g.l2_p0[k] = (uint16_t)p0; g.l2_p1[k] = (uint16_t)p1;
+            g.l2_off[k] = (uint16_t)(lut_bytes / 2);
+            lut_bytes += (p1 - p0) * 128;
+            if (lut_bytes > PJD_LUT_LDS_MAX) { tables_parallel_ok = false; lut_bytes = (uint32_t)nt * PJD_L1_BYTES; }
+        }
 
         // ---- restart segments and routing
         const uint32_t RI = d.restart_interval;
         const bool luma11 = (g.hs == 1 && g.vs == 1);
         const bool std_rule = (d.flags & PJD_F_STANDARD_RESTART) != 0;
-        bool sequential = (d.flags & PJD_F_FORCE_SEQUENTIAL) != 0;
+        bool sequential = (d.flags & PJD_F_FORCE_SEQUENTIAL) != 0 || !tables_parallel_ok;
         uint32_t nseg_total = 1;
         if (RI != 0) {
             nseg_total = (g.n_mcu + RI - 1) / RI;
@@ -162,6 +185,10 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         }
         h.sequential = sequential;
         if (sequential) g.flags |= PJD_IF_SEQUENTIAL;
+        g.lut_bytes = sequential ? 0 : (uint32_t)align_up(lut_bytes, 16);
+        g.lut_off16 = (uint32_t)(lut_off / 16);
+        lut_off += g.lut_bytes;
+        if (g.lut_bytes > P.max_lut_bytes) P.max_lut_bytes = g.lut_bytes;
 
         uint64_t byte_lo = 0, byte_hi = d.ecs_len;
         if (RI != 0 && !sequential) {
@@ -254,6 +281,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.dense_du = dense_seq + dense_fb;
     P.out_buf_bytes = align_up(out_off, 256);
     P.n_dcblk = dcblk;
+    P.lut_buf_bytes = align_up(lut_off + 16, 256);
     if (P.ecs_buf_bytes >= (1ull << 40)) { err = "batch bitstream too large"; return PJD_E_ARG; }
     return PJD_OK;
 }

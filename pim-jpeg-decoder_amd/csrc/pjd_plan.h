@@ -33,6 +33,8 @@ struct PjdPlan {
     uint64_t dense_du = 0;                 // data units of the dense scratch (exact-kernel images + one fallback image)
     uint64_t out_buf_bytes = 0;
     uint64_t n_dcblk = 0;
+    uint64_t lut_buf_bytes = 0;            // decode-table blobs of all parallel-path images
+    uint32_t max_lut_bytes = 0;            // largest blob (dynamic LDS of the Huffman kernels)
     uint64_t pixels = 0, ecs_bytes = 0, out_bytes = 0;
 };
 
