@@ -158,6 +158,13 @@ int  pjd_batch_capture(pjd_batch *b);       /* record the decode as a hipGraph; 
                                                pjd_batch_decode calls replay it               */
 int  pjd_batch_sync(pjd_batch *b);
 int  pjd_batch_download(pjd_batch *b, uint8_t *const *out, int32_t *status);
+/* All pictures in ONE device-to-host copy: `host` receives the batch's output buffer as it lies
+ * in HBM (picture i at pjd_batch_output_offset(b, i), 256-byte aligned, pjd_batch_packed_size(b)
+ * bytes in total).  Give it memory from pjd_host_alloc for a full-rate PCIe transfer.  This is the
+ * copy(batch.mcus, "mcus") of decoder_host.cpp:308 for a whole batch.                           */
+int  pjd_batch_download_packed(pjd_batch *b, uint8_t *host, uint64_t capacity, int32_t *status);
+uint64_t pjd_batch_packed_size(pjd_batch *b);
+uint64_t pjd_batch_output_offset(pjd_batch *b, int image);
 int  pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info);
 uint64_t pjd_batch_output_size(pjd_batch *b, int image);
 void *pjd_batch_device_output(pjd_batch *b, int image);      /* device pointer (HBM)          */
@@ -178,6 +185,10 @@ int  pjd_exec_dpu_payload(pjd_ctx *ctx, const uint32_t *metadata, int16_t *mcus,
 /* Host-only planning: what a batch of these images would occupy (no device needed).
  * Fills everything in `info` except device_bytes / n_fallback.                   */
 int  pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pjd_batch_info *info);
+
+/* Page-locked host memory (hipHostMalloc) for pjd_batch_download_packed; NULL on failure.       */
+void *pjd_host_alloc(uint64_t bytes);
+void pjd_host_free(void *p);
 
 /* Size in bytes of one picture in a given output format.                      */
 uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_format);

@@ -1,0 +1,67 @@
+/*
+ * pjd_pipeline.h -- C ABI of the pipelined batcher (libpjdpipe.so): files (or in-memory JPEGs) in,
+ * BMP / RGB pictures out, with scan, H2D, GPU decode, D2H and the consumer of the pictures all
+ * overlapping.
+ *
+ * It replaces the reference's producer/consumer pair
+ *     mcu_prepare()   src/decoder_host.cpp:104-211   (producer thread: read_JPEG + Huffman + batching)
+ *     offloading()    src/decoder_host.cpp:213-350   (consumer thread: DPU copy/exec/copy + write_BMP)
+ *     main()          src/decoder_host.cpp:396-399   (the two std::threads and their queue)
+ * with
+ *     scan workers  -> batches of `batch_images` consecutive inputs
+ *     GPU slots     -> each slot owns a pjd_ctx (its own HIP stream) and runs
+ *                      create / upload / decode / packed download for one batch at a time, so
+ *                      the H2D of one batch, the kernels of another and the D2H of a third overlap
+ *     sink workers  -> hand every picture to the caller's sink (the CLI writes "<stem>.bmp")
+ *
+ * Inputs keep their order inside a batch; batches complete in any order.  Error behaviour is the
+ * reference's: a file the scanner rejects produces its messages and no picture; a Huffman error
+ * produces the message and the partial picture (src/decoder_host.cpp:120-123,181).
+ */
+#ifndef PJD_PIPELINE_H
+#define PJD_PIPELINE_H
+
+#include "pjd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Called once per input, from a sink worker thread (several may run at once):
+ *   index   position of the input in the caller's list
+ *   name    the path / name given for it
+ *   log     what the reference would have printed while parsing this file ("" if nothing)
+ *   status  -1: rejected by the scanner (no picture), -2: the GPU batch failed (no picture),
+ *           else PJD_ST_* of the entropy decode (0 = clean; > 0: partial picture, message =
+ *           pjd_status_string(status))
+ *   data/len  the picture in the requested output format; valid only during the call          */
+typedef void (*pjd_pipe_sink)(void *user, int index, const char *name, const char *log, int status,
+                              const uint8_t *data, uint64_t len);
+
+typedef struct pjd_pipe_opts {
+    int32_t device;          /* HIP device ordinal                                             */
+    int32_t out_format;      /* PJD_OUT_BMP / PJD_OUT_RGB8                                     */
+    int32_t batch_images;    /* inputs per GPU batch               (0 -> 1024)                 */
+    int32_t scan_threads;    /* JPEG scanner workers               (0 -> 4)                    */
+    int32_t slots;           /* GPU batches in flight              (0 -> 3)                    */
+    int32_t sink_threads;    /* workers calling the sink           (0 -> 4)                    */
+    pjd_pipe_sink sink;      /* may be NULL (pictures are dropped: measurement only)           */
+    void *sink_user;
+} pjd_pipe_opts;
+
+typedef struct pjd_pipe_stats {
+    double wall_s;           /* whole run                                                      */
+    double scan_s, create_s, upload_s, exec_s, download_s, sink_s;   /* summed over workers   */
+    uint64_t n_inputs, n_decoded, n_rejected, n_batches, n_batch_failures;
+    uint64_t pixels, in_bytes, ecs_bytes, out_bytes;
+} pjd_pipe_stats;
+
+/* Returns PJD_OK, PJD_E_NODEVICE if no slot could open the device, PJD_E_ARG.                 */
+int pjd_pipe_run_files(const char *const *paths, int n, const pjd_pipe_opts *opts, pjd_pipe_stats *stats);
+int pjd_pipe_run_memory(const uint8_t *const *data, const uint64_t *len, const char *const *names, int n,
+                        const pjd_pipe_opts *opts, pjd_pipe_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

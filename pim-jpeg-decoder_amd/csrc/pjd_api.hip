@@ -15,15 +15,41 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pjd.h"
 #include "pjd_kernels.h"
 #include "pjd_plan.h"
 
+// Buffers of destroyed batches are kept per context and handed to the next batch (a steady stream of
+// batches then allocates nothing); bounded by pool_cap, freed at pjd_close.
+struct PoolBlock { void *p; size_t bytes; };
+struct Pool {
+    std::vector<PoolBlock> free_blocks;
+    size_t bytes = 0;
+    void *take(size_t want, size_t &got)
+    {
+        int best = -1;
+        for (size_t k = 0; k < free_blocks.size(); k++) {
+            const size_t sz = free_blocks[k].bytes;
+            if (sz >= want && sz <= 2 * want + (1u << 20) && (best < 0 || sz < free_blocks[best].bytes)) best = (int)k;
+        }
+        if (best < 0) return nullptr;
+        void *p = free_blocks[best].p;
+        got = free_blocks[best].bytes;
+        bytes -= got;
+        free_blocks.erase(free_blocks.begin() + best);
+        return p;
+    }
+    void give(void *p, size_t sz) { free_blocks.push_back({p, sz}); bytes += sz; }
+};
+
 struct pjd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    Pool dev_pool, pin_pool;
+    size_t pool_cap = (size_t)64 << 30;   // bytes of HBM kept for reuse (PJD_POOL_GB)
     std::string err;
     bool force_sequential = false;
     uint32_t sub_bytes_override = 0;
@@ -40,22 +66,37 @@ struct pjd_ctx {
 
 namespace {
 
-template <class T>
-int dev_upload(pjd_ctx *ctx, T *&dptr, const std::vector<T> &v, size_t min_elems = 1)
+int pool_dev_alloc(pjd_ctx *ctx, void **out, size_t bytes, std::vector<PoolBlock> &owned)
 {
-    size_t n = v.size() > min_elems ? v.size() : min_elems;
-    HIP_TRY(ctx, hipMalloc((void **)&dptr, n * sizeof(T)));
-    HIP_TRY(ctx, hipMemsetAsync(dptr, 0, n * sizeof(T), ctx->stream));
-    if (!v.empty()) HIP_TRY(ctx, hipMemcpyAsync(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (bytes == 0) bytes = 16;
+    size_t got = 0;
+    void *p = ctx->dev_pool.take(bytes, got);
+    if (!p) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess && !ctx->dev_pool.free_blocks.empty()) {          // give cached memory back and retry
+            for (PoolBlock &k : ctx->dev_pool.free_blocks) hipFree(k.p);
+            ctx->dev_pool.free_blocks.clear(); ctx->dev_pool.bytes = 0;
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return PJD_E_NOMEM; }
+        got = bytes;
+    }
+    owned.push_back({p, got});
+    *out = p;
     return PJD_OK;
 }
 
-template <class T>
-int dev_alloc(pjd_ctx *ctx, T *&dptr, size_t n, uint64_t &total)
+int pool_pin_alloc(pjd_ctx *ctx, void **out, size_t bytes, std::vector<PoolBlock> &owned)
 {
-    if (n == 0) n = 1;
-    HIP_TRY(ctx, hipMalloc((void **)&dptr, n * sizeof(T)));
-    total += n * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    size_t got = 0;
+    void *p = ctx->pin_pool.take(bytes, got);
+    if (!p) {
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc failed"; return PJD_E_NOMEM; }
+        got = bytes;
+    }
+    owned.push_back({p, got});
+    *out = p;
     return PJD_OK;
 }
 
@@ -84,6 +125,7 @@ struct pjd_batch {
     int32_t *h_status = nullptr;         // pinned
     std::vector<uint32_t> iwg_base, iwg_count;   // per image, into plan.iwgs
     std::vector<uint32_t> seq_list;      // what d_seq_list holds
+    std::vector<PoolBlock> dev_blocks, pin_blocks;   // everything this batch took from the context's pools
     uint64_t device_bytes = 0;
     bool uploaded = false, decoded = false, settled = false;
     int n_fallback = 0;
@@ -112,6 +154,8 @@ int pjd_open(int device_ordinal, pjd_ctx **out)
     }
     const char *fs = std::getenv("PJD_FORCE_SEQUENTIAL");
     c->force_sequential = fs && fs[0] == '1';
+    const char *pg = std::getenv("PJD_POOL_GB");
+    if (pg) c->pool_cap = (size_t)std::atoll(pg) << 30;
     const char *sb = std::getenv("PJD_SUB_BYTES");
     c->sub_bytes_override = sb ? (uint32_t)std::atoi(sb) : 0;
     *out = c;
@@ -123,6 +167,8 @@ void pjd_close(pjd_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+    for (PoolBlock &k : ctx->dev_pool.free_blocks) hipFree(k.p);
+    for (PoolBlock &k : ctx->pin_pool.free_blocks) hipHostFree(k.p);
     delete ctx;
 }
 
@@ -152,14 +198,15 @@ void pjd_batch_destroy(pjd_batch *b)
     hipStreamSynchronize(b->ctx->stream);
     if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
     if (b->graph) hipGraphDestroy(b->graph);
-    void *ptrs[] = { b->d_images, b->d_raw, b->d_qtab, b->d_segs, b->d_subs, b->d_hwgs, b->d_iwgs, b->d_iwgs_dense, b->d_ecs,
-                     b->dev.ent, b->dev.du_end, b->dev.seg_ent, b->dev.dcv, b->dev.wg_eagg, b->dev.wg_ent_in,
-                     b->d_dcblk_image, b->d_seq_list, b->d_fb_list, b->d_fb_iwgs, b->d_status_init,
-                     b->dev.luts, b->dev.coef, b->dev.out, b->dev.status, b->dev.sub_exit, b->dev.sub_cnt, b->dev.sub_chk,
-                     b->dev.wg_entry, b->dev.wg_exit, b->dev.wg_agg, b->dev.wg_du_in, b->dev.dc_agg, b->dev.dc_carry, b->dev.stats };
-    for (void *p : ptrs) if (p) hipFree(p);
-    if (b->h_ecs) hipHostFree(b->h_ecs);
-    if (b->h_status) hipHostFree(b->h_status);
+    pjd_ctx *ctx = b->ctx;
+    for (PoolBlock &k : b->dev_blocks) {
+        if (ctx->dev_pool.bytes + k.bytes <= ctx->pool_cap) ctx->dev_pool.give(k.p, k.bytes);
+        else hipFree(k.p);
+    }
+    for (PoolBlock &k : b->pin_blocks) {
+        if (ctx->pin_pool.bytes + k.bytes <= ctx->pool_cap / 4) ctx->pin_pool.give(k.p, k.bytes);
+        else hipHostFree(k.p);
+    }
     delete b;
 }
 
@@ -177,11 +224,18 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     // pinned staging for the packed bitstreams; filled now so the caller's buffers can go away
     rc = PJD_OK;
     auto fail = [&](int code) { pjd_batch_destroy(b); return code; };
-    if (hipHostMalloc((void **)&b->h_ecs, P.ecs_buf_bytes, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(ecs)"; return fail(PJD_E_NOMEM); }
-    std::memset(b->h_ecs, 0, P.ecs_buf_bytes);
-    for (int i = 0; i < n_images; i++)
-        if (P.host[i].ecs_copy_len) std::memcpy(b->h_ecs + P.images[i].ecs_off, P.host[i].ecs_src, P.host[i].ecs_copy_len);
-    if (hipHostMalloc((void **)&b->h_status, sizeof(int32_t) * (n_images + 1), hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc(status)"; return fail(PJD_E_NOMEM); }
+    if (pool_pin_alloc(ctx, (void **)&b->h_ecs, P.ecs_buf_bytes, b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
+    {   // streams at their offsets, zeros in between (every stream is followed by >= 48 zero bytes)
+        uint64_t pos = 0;
+        for (int i = 0; i < n_images; i++) {
+            const uint64_t off = P.images[i].ecs_off, len = P.host[i].ecs_copy_len;
+            if (off > pos) std::memset(b->h_ecs + pos, 0, off - pos);
+            if (len) std::memcpy(b->h_ecs + off, P.host[i].ecs_src, len);
+            pos = off + len;
+        }
+        std::memset(b->h_ecs + pos, 0, P.ecs_buf_bytes - pos);
+    }
+    if (pool_pin_alloc(ctx, (void **)&b->h_status, sizeof(int32_t) * (n_images + 1), b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
 
     // per-image IDCT work-list ranges (for the fallback re-run)
     b->iwg_base.assign(n_images, 0); b->iwg_count.assign(n_images, 0);
@@ -193,6 +247,15 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
 
     uint64_t &tot = b->device_bytes;
 #define TRY_RC(x) do { int rc_ = (x); if (rc_ != PJD_OK) return fail(rc_); } while (0)
+    auto dev_alloc = [&](pjd_ctx *c, auto *&dptr, size_t n, uint64_t &total) {
+        using T = std::remove_reference_t<decltype(*dptr)>;
+        if (n == 0) n = 1;
+        void *p = nullptr;
+        const int r = pool_dev_alloc(c, &p, n * sizeof(T), b->dev_blocks);
+        dptr = (T *)p;
+        total += n * sizeof(T);
+        return r;
+    };
     TRY_RC(dev_alloc(ctx, b->d_images, P.images.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_raw, P.tables.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_qtab, P.qtab.size(), tot));
@@ -449,6 +512,40 @@ int pjd_batch_download(pjd_batch *b, uint8_t *const *out, int32_t *status)
     return PJD_OK;
 }
 
+int pjd_batch_download_packed(pjd_batch *b, uint8_t *host, uint64_t capacity, int32_t *status)
+{
+    if (!b || !host) return PJD_E_ARG;
+    if (!b->decoded) { b->ctx->err = "download before decode"; return PJD_E_STATE; }
+    pjd_ctx *ctx = b->ctx;
+    PjdPlan &P = b->plan;
+    hipSetDevice(ctx->device);
+    if (capacity < P.out_buf_bytes) { ctx->err = "download_packed: buffer smaller than pjd_batch_packed_size"; return PJD_E_ARG; }
+    int rc = settle(b);
+    if (rc != PJD_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host, b->dev.out, P.out_buf_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (status)
+        for (size_t i = 0; i < P.images.size(); i++) status[i] = b->h_status[i] & 0xFF;
+    return PJD_OK;
+}
+
+uint64_t pjd_batch_packed_size(pjd_batch *b) { return b ? b->plan.out_buf_bytes : 0; }
+
+uint64_t pjd_batch_output_offset(pjd_batch *b, int image)
+{
+    if (!b || image < 0 || (size_t)image >= b->plan.images.size()) return 0;
+    return b->plan.images[image].out_off;
+}
+
+void *pjd_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void pjd_host_free(void *p) { if (p) hipHostFree(p); }
+
 int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
 {
     if (!b || !info) return PJD_E_ARG;
@@ -469,7 +566,8 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     info->n_huff_workgroups = P.hwgs.size();
     if (std::getenv("PJD_DEBUG_STATS"))
         std::fprintf(stderr, "[pjd stats] setup_cyc %llu round0_cyc %llu rounds_cyc %llu round0_maxiters %llu | realtime(10ns) setup %llu round0 %llu rounds %llu | waves %zu\n",
-                     st[4], st[5], st[6], st[7], st[8], st[9], st[10], P.hwgs.size());
+                     st[4], st[5], st[6], st[7], st[8], st[9], st[10], P.hwgs.size()),
+        std::fprintf(stderr, "[pjd stats] max wave life(10ns) %llu max round0 %llu waves>0.5ms %llu >0.8ms %llu >1.0ms %llu\n", st[11], st[12], st[13], st[14], st[15]);
     return PJD_OK;
 }
 

@@ -371,6 +371,11 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_sync(PjdDevBatch 
         if (t == 0 && B.stats) {
             atomicAdd(B.stats + 4, tc1 - tc0); atomicAdd(B.stats + 5, tc2 - tc1); atomicAdd(B.stats + 6, tc3 - tc2); atomicAdd(B.stats + 7, (unsigned long long)mx);
             atomicAdd(B.stats + 8, tr1 - tr0); atomicAdd(B.stats + 9, tr2 - tr1); atomicAdd(B.stats + 10, tr3 - tr2);
+            atomicMax(B.stats + 11, tr3 - tr0); atomicMax(B.stats + 12, tr2 - tr1);
+            // histogram of wave lifetimes in 100 us buckets is too wide for 16 slots: count waves above 0.5 / 0.8 / 1.0 ms
+            if (tr3 - tr0 > 50000) atomicAdd(B.stats + 13, 1ull);
+            if (tr3 - tr0 > 80000) atomicAdd(B.stats + 14, 1ull);
+            if (tr3 - tr0 > 100000) atomicAdd(B.stats + 15, 1ull);
         }
     }
     if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);

@@ -11,7 +11,10 @@
 // producer/consumer pair is a scan stage followed by batched GPU decodes, and the four DPU cycle
 // counters become per-kernel milliseconds measured with HIP events.
 //
-// Extensions (do not change the default behaviour): --device N, --batch M (images per GPU batch).
+// Extensions (do not change the default behaviour): --device N, --batch M (images per GPU batch),
+// --pipeline [--slots S --scan-threads T --write-threads W]: the pipelined batcher of
+// include/pjd_pipeline.h (scan, copies, kernels and BMP writes overlap; messages are printed in input
+// order at the end instead of interleaved).
 #include <sys/stat.h>
 #include <time.h>
 
@@ -25,6 +28,7 @@
 
 #include "../../include/pjd.h"
 #include "../../include/pjd_host.h"
+#include "../../include/pjd_pipeline.h"
 
 static double now_s()
 {
@@ -39,14 +43,70 @@ static std::string bmp_name(const std::string &in)
     return pos == std::string::npos ? in + ".bmp" : in.substr(0, pos) + ".bmp";
 }
 
+// ---- --pipeline mode ---------------------------------------------------------------------------
+struct PipeOut {
+    std::vector<std::string> messages;       // per input, printed in input order afterwards
+};
+
+static void pipe_sink(void *user, int index, const char *name, const char *log, int status, const uint8_t *data, uint64_t len)
+{
+    PipeOut *po = (PipeOut *)user;
+    std::string &m = po->messages[(size_t)index];    // one call per index: no lock needed
+    m = log;
+    if (status == -2) m += std::string(name) + ": Error - GPU batch failed\n";
+    if (status > 0) m += std::string(name) + ": " + pjd_status_string(status) + "\n";
+    if (data) {
+        const std::string out = bmp_name(name);
+        if (pjd_write_file(out.c_str(), data, len) != 0) m += out + ": Error - Unable to create BMP file\n";
+    }
+}
+
+static int run_pipeline(const std::vector<std::string> &files, int device, int batch_images, int slots, int scan_threads, int write_threads)
+{
+    std::vector<const char *> paths;
+    for (const std::string &f : files) paths.push_back(f.c_str());
+    PipeOut po;
+    po.messages.resize(files.size());
+    pjd_pipe_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.device = device; o.out_format = PJD_OUT_BMP; o.batch_images = batch_images;
+    o.slots = slots; o.scan_threads = scan_threads; o.sink_threads = write_threads;
+    o.sink = pipe_sink; o.sink_user = &po;
+    pjd_pipe_stats st;
+    const int rc = pjd_pipe_run_files(paths.data(), (int)paths.size(), &o, &st);
+    if (rc == PJD_E_NODEVICE) {
+        std::cout << "Error - no usable MI355X (gfx950) device (pjd_open returned " << rc << ")\n";
+        return 2;
+    }
+    std::cout << "1 MI355X device is allocated\n";
+    for (const std::string &m : po.messages) std::cout << m;
+    std::cout << "\nProfiles:\n";
+    std::cout << "End-to-end execution time: " << st.wall_s << "s\n";
+    std::cout << "MCU Offloader execution time (summed over overlapping workers): \n";
+    std::cout << " - JPEG scan time: " << st.scan_s << "s\n";
+    std::cout << " - batch planning time: " << st.create_s << "s\n";
+    std::cout << " - CPU-to-GPU transfer time: " << st.upload_s << "s\n";
+    std::cout << " - GPU execution time: " << st.exec_s << "s\n";
+    std::cout << " - GPU-to-CPU transfer time: " << st.download_s << "s\n";
+    std::cout << " - BMP write time: " << st.sink_s << "s\n";
+    std::cout << " - Total " << st.n_batches << " calls, " << st.n_decoded << " pictures, " << st.pixels / 1e6 << " MPixels\n";
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int device = 0;
     size_t batch_images = 1024;
+    bool pipeline = false;
+    int slots = 0, scan_threads = 0, write_threads = 0;
     std::vector<std::string> files;
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch_images = (size_t)std::atoll(argv[++i]);
+        else if (!std::strcmp(argv[i], "--pipeline")) pipeline = true;
+        else if (!std::strcmp(argv[i], "--slots") && i + 1 < argc) slots = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--scan-threads") && i + 1 < argc) scan_threads = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--write-threads") && i + 1 < argc) write_threads = std::atoi(argv[++i]);
         else files.push_back(argv[i]);
     }
     if (files.empty()) {
@@ -60,6 +120,11 @@ int main(int argc, char **argv)
         sized.emplace_back(stat(f.c_str(), &st) == 0 ? (long long)st.st_size : 0LL, f);
     }
     std::stable_sort(sized.begin(), sized.end(), [](const std::pair<long long, std::string> &a, const std::pair<long long, std::string> &b) { return a.first < b.first; });
+    if (pipeline) {
+        std::vector<std::string> ordered;
+        for (const auto &p : sized) ordered.push_back(p.second);
+        return run_pipeline(ordered, device, (int)batch_images, slots, scan_threads, write_threads);
+    }
 
     pjd_ctx *ctx = nullptr;
     int rc = pjd_open(device, &ctx);

@@ -1,0 +1,283 @@
+// pjd_pipeline.cpp -- the pipelined batcher behind include/pjd_pipeline.h (libpjdpipe.so).
+//
+// Stands where the reference has its producer thread (mcu_prepare, reference src/decoder_host.cpp:104-211),
+// its consumer thread (offloading, :213-350) and the std::queue<Batch> between them (:25-38):
+//
+//   scan workers --(batch complete)--> ready queue --> GPU slots --(pictures)--> sink queue --> sink workers
+//
+// A batch is `batch_images` CONSECUTIVE inputs, so its composition does not depend on thread timing.
+// Every GPU slot owns a pjd_ctx, i.e. its own HIP stream and its own buffer pool: while one slot's
+// kernels run, another slot's bitstreams go up and a third slot's pictures come down.  Pictures leave
+// the GPU in one packed copy into page-locked memory (pjd_batch_download_packed).
+#include <sys/stat.h>
+#include <time.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pjd_host.h"
+#include "../../include/pjd_pipeline.h"
+
+namespace {
+
+double now_s()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+struct Input {
+    const char *path = nullptr;          // file input
+    const uint8_t *data = nullptr;       // memory input
+    uint64_t len = 0;
+    const char *name = "";
+    pjd_scanned *sc = nullptr;
+    int scan_rc = 2;
+};
+
+struct Job {                             // one batch: inputs [first, first + count)
+    int first = 0, count = 0;
+    std::atomic<int> scanned{0};
+};
+
+struct SinkTask {
+    int index;
+    int status;
+    const uint8_t *data;
+    uint64_t len;
+    std::atomic<int> *latch;             // counts the tasks of one batch still running (may be null)
+};
+
+template <class T>
+struct Queue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<T> q;
+    bool closed = false;
+    void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(v)); } cv.notify_one(); }
+    void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+    bool pop(T &out)
+    {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        out = std::move(q.front());
+        q.pop_front();
+        return true;
+    }
+};
+
+struct Pipe {
+    pjd_pipe_opts o;
+    std::vector<Input> in;
+    std::vector<std::unique_ptr<Job>> jobs;
+    std::atomic<int> next_input{0};
+    Queue<int> ready;                    // job indices whose inputs are all scanned
+    Queue<SinkTask> sinkq;
+    std::mutex stat_m, latch_m;
+    std::condition_variable latch_cv;
+    pjd_pipe_stats st{};
+    std::atomic<int> slots_open{0};
+
+    void add(double pjd_pipe_stats::*f, double v) { std::lock_guard<std::mutex> l(stat_m); st.*f += v; }
+
+    void scan_worker()
+    {
+        double t_scan = 0;
+        uint64_t in_bytes = 0;
+        for (;;) {
+            const int i = next_input.fetch_add(1);
+            if (i >= (int)in.size()) break;
+            Input &x = in[i];
+            const double t0 = now_s();
+            if (x.path) {
+                struct stat sb;
+                if (stat(x.path, &sb) == 0) in_bytes += (uint64_t)sb.st_size;
+                x.scan_rc = pjd_scan_file(x.path, &x.sc);
+            } else {
+                in_bytes += x.len;
+                x.scan_rc = pjd_scan_memory(x.data, x.len, x.name, &x.sc);
+            }
+            t_scan += now_s() - t0;
+            Job &j = *jobs[i / o.batch_images];
+            if (j.scanned.fetch_add(1) + 1 == j.count) ready.push(i / o.batch_images);
+        }
+        std::lock_guard<std::mutex> l(stat_m);
+        st.scan_s += t_scan;
+        st.in_bytes += in_bytes;
+    }
+
+    void emit(int index, int status, const uint8_t *data, uint64_t len, std::atomic<int> *latch)
+    {
+        if (!o.sink) return;
+        if (latch) latch->fetch_add(1);
+        sinkq.push(SinkTask{index, status, data, len, latch});
+    }
+
+    void slot_worker()
+    {
+        pjd_ctx *ctx = nullptr;
+        if (pjd_open(o.device, &ctx) == PJD_OK) slots_open.fetch_add(1);
+        uint8_t *pinned = nullptr;
+        uint64_t pinned_cap = 0;
+        std::atomic<int> latch{0};
+        int j;
+        while (ready.pop(j)) {
+            Job &job = *jobs[j];
+            std::vector<int> idx;                          // inputs of this batch the scanner accepted
+            std::vector<pjd_image_desc> descs;
+            uint64_t rejected = 0;
+            for (int i = job.first; i < job.first + job.count; i++) {
+                Input &x = in[i];
+                if (x.scan_rc == 0 && x.sc) { idx.push_back(i); descs.push_back(*pjd_scanned_desc(x.sc)); }
+                else { rejected++; emit(i, -1, nullptr, 0, &latch); }
+            }
+            double t_create = 0, t_up = 0, t_exec = 0, t_down = 0;
+            uint64_t pixels = 0, ecs = 0, outb = 0, decoded = 0;
+            bool failed = false;
+            if (!idx.empty()) {
+                pjd_batch *b = nullptr;
+                int rc = ctx ? PJD_OK : PJD_E_NODEVICE;
+                double t0 = now_s();
+                if (rc == PJD_OK) rc = pjd_batch_create(ctx, descs.data(), (int)descs.size(), o.out_format, &b);
+                t_create = now_s() - t0; t0 = now_s();
+                if (rc == PJD_OK) rc = pjd_batch_upload(b);
+                t_up = now_s() - t0; t0 = now_s();
+                if (rc == PJD_OK) rc = pjd_batch_decode(b);
+                if (rc == PJD_OK) rc = pjd_batch_sync(b);
+                t_exec = now_s() - t0; t0 = now_s();
+                std::vector<int32_t> status(idx.size(), 0);
+                if (rc == PJD_OK) {
+                    const uint64_t need = pjd_batch_packed_size(b);
+                    if (need > pinned_cap) {
+                        pjd_host_free(pinned);
+                        pinned_cap = need + need / 4;
+                        pinned = (uint8_t *)pjd_host_alloc(pinned_cap);
+                        if (!pinned) { pinned_cap = 0; rc = PJD_E_NOMEM; }
+                    }
+                    if (rc == PJD_OK) rc = pjd_batch_download_packed(b, pinned, pinned_cap, status.data());
+                }
+                t_down = now_s() - t0;
+                if (rc == PJD_OK) {
+                    pjd_batch_info info;
+                    if (pjd_batch_get_info(b, &info) == PJD_OK) { pixels = info.pixels; ecs = info.ecs_bytes; outb = info.out_bytes; }
+                    for (size_t k = 0; k < idx.size(); k++)
+                        emit(idx[k], status[k], pinned + pjd_batch_output_offset(b, (int)k), pjd_batch_output_size(b, (int)k), &latch);
+                    decoded = idx.size();
+                } else {
+                    failed = true;
+                    for (size_t k = 0; k < idx.size(); k++) emit(idx[k], -2, nullptr, 0, &latch);
+                }
+                if (b) pjd_batch_destroy(b);
+            }
+            // the pinned buffer and the scan logs are referenced by the sink tasks of this batch
+            {
+                std::unique_lock<std::mutex> l(latch_m);
+                latch_cv.wait(l, [&] { return latch.load() == 0; });
+            }
+            for (int i = job.first; i < job.first + job.count; i++)
+                if (in[i].sc) { pjd_scanned_free(in[i].sc); in[i].sc = nullptr; }
+            std::lock_guard<std::mutex> l(stat_m);
+            st.create_s += t_create; st.upload_s += t_up; st.exec_s += t_exec; st.download_s += t_down;
+            st.n_batches++; st.n_batch_failures += failed ? 1 : 0;
+            st.n_decoded += decoded; st.n_rejected += rejected;
+            st.pixels += pixels; st.ecs_bytes += ecs; st.out_bytes += outb;
+        }
+        pjd_host_free(pinned);
+        if (ctx) pjd_close(ctx);
+    }
+
+    void sink_worker()
+    {
+        double t_sink = 0;
+        SinkTask t;
+        while (sinkq.pop(t)) {
+            const Input &x = in[t.index];
+            const double t0 = now_s();
+            const char *log = x.sc ? pjd_scanned_log(x.sc) : "";
+            std::string opened;
+            if (x.scan_rc == 2) {                          // the reference's message for an unreadable file (jpeg_scanner.cpp:351)
+                opened = std::string(x.name) + ": Error - Error opening input file\n" + x.name + ": Error - Invalid JPEG\n";
+                log = opened.c_str();
+            }
+            o.sink(o.sink_user, t.index, x.name, log, t.status, t.data, t.len);
+            t_sink += now_s() - t0;
+            if (t.latch && t.latch->fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> l(latch_m);
+                latch_cv.notify_all();
+            }
+        }
+        add(&pjd_pipe_stats::sink_s, t_sink);
+    }
+
+    int run()
+    {
+        const double t0 = now_s();
+        const int n = (int)in.size();
+        const int nb = (n + o.batch_images - 1) / o.batch_images;
+        for (int k = 0; k < nb; k++) {
+            jobs.emplace_back(new Job);
+            jobs[k]->first = k * o.batch_images;
+            jobs[k]->count = (k + 1) * o.batch_images <= n ? o.batch_images : n - k * o.batch_images;
+        }
+        st.n_inputs = (uint64_t)n;
+        std::vector<std::thread> scanners, slots, sinks;
+        for (int k = 0; k < o.sink_threads && o.sink; k++) sinks.emplace_back([this] { sink_worker(); });
+        for (int k = 0; k < o.slots; k++) slots.emplace_back([this] { slot_worker(); });
+        for (int k = 0; k < o.scan_threads; k++) scanners.emplace_back([this] { scan_worker(); });
+        for (std::thread &t : scanners) t.join();
+        ready.close();                                     // every job has been pushed by now
+        for (std::thread &t : slots) t.join();
+        sinkq.close();
+        for (std::thread &t : sinks) t.join();
+        st.wall_s = now_s() - t0;
+        return slots_open.load() > 0 || n == 0 ? PJD_OK : PJD_E_NODEVICE;
+    }
+};
+
+int run_pipe(Pipe &p, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
+{
+    if (!opts) return PJD_E_ARG;
+    p.o = *opts;
+    if (p.o.batch_images <= 0) p.o.batch_images = 1024;
+    if (p.o.scan_threads <= 0) p.o.scan_threads = 4;
+    if (p.o.slots <= 0) p.o.slots = 3;
+    if (p.o.sink_threads <= 0) p.o.sink_threads = 4;
+    if (p.o.out_format != PJD_OUT_BMP && p.o.out_format != PJD_OUT_RGB8) return PJD_E_ARG;
+    const int rc = p.run();
+    if (stats) *stats = p.st;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pjd_pipe_run_files(const char *const *paths, int n, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
+{
+    if (n < 0 || (n > 0 && !paths)) return PJD_E_ARG;
+    Pipe p;
+    p.in.resize((size_t)n);
+    for (int i = 0; i < n; i++) { p.in[i].path = paths[i]; p.in[i].name = paths[i]; }
+    return run_pipe(p, opts, stats);
+}
+
+int pjd_pipe_run_memory(const uint8_t *const *data, const uint64_t *len, const char *const *names, int n,
+                        const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
+{
+    if (n < 0 || (n > 0 && (!data || !len))) return PJD_E_ARG;
+    Pipe p;
+    p.in.resize((size_t)n);
+    for (int i = 0; i < n; i++) { p.in[i].data = data[i]; p.in[i].len = len[i]; p.in[i].name = names && names[i] ? names[i] : ""; }
+    return run_pipe(p, opts, stats);
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 LIB_DIR = os.path.join(_PKG, "lib")
 LIBPJD = os.path.join(LIB_DIR, "libpjd.so")
 LIBHOST = os.path.join(LIB_DIR, "libpjdhost.so")
+LIBPIPE = os.path.join(LIB_DIR, "libpjdpipe.so")
 
 OUT_RGB8, OUT_BMP = 0, 1
 F_STANDARD_RESTART, F_FORCE_SEQUENTIAL = 1, 2
@@ -119,6 +120,15 @@ def dev_lib():
         L.pjd_batch_download.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32)]
         L.pjd_batch_get_info.restype = i32
         L.pjd_batch_get_info.argtypes = [vp, C.POINTER(BatchInfo)]
+        L.pjd_batch_download_packed.restype = i32
+        L.pjd_batch_download_packed.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_int32)]
+        L.pjd_batch_packed_size.restype = C.c_uint64
+        L.pjd_batch_packed_size.argtypes = [vp]
+        L.pjd_batch_output_offset.restype = C.c_uint64
+        L.pjd_batch_output_offset.argtypes = [vp, i32]
+        L.pjd_host_alloc.restype = vp
+        L.pjd_host_alloc.argtypes = [C.c_uint64]
+        L.pjd_host_free.argtypes = [vp]
         L.pjd_batch_output_size.restype = C.c_uint64
         L.pjd_batch_output_size.argtypes = [vp, i32]
         L.pjd_batch_device_output.restype = vp
@@ -295,6 +305,98 @@ class Batch:
         if self.out_format == OUT_RGB8:
             outs = [o.reshape(int(self._descs[i].height), int(self._descs[i].width), 3) for i, o in enumerate(outs)]
         return outs, [int(st[i]) for i in range(self.n)]
+
+
+    def download_packed(self):
+        """All pictures in one D2H copy into page-locked memory; returns (list of arrays, statuses)."""
+        size = int(self.L.pjd_batch_packed_size(self._h))
+        host = self.L.pjd_host_alloc(size)
+        if not host:
+            raise PjdError("pjd_host_alloc failed")
+        try:
+            st = (C.c_int32 * max(self.n, 1))()
+            self.ctx._check(self.L.pjd_batch_download_packed(self._h, host, size, st), "pjd_batch_download_packed")
+            whole = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint8)), shape=(size,))
+            outs = []
+            for i in range(self.n):
+                off, n = int(self.L.pjd_batch_output_offset(self._h, i)), self.output_size(i)
+                outs.append(whole[off:off + n].copy())
+        finally:
+            self.L.pjd_host_free(host)
+        return outs, [int(st[i]) for i in range(self.n)]
+
+
+# ---- pipelined batcher (include/pjd_pipeline.h) ---------------------------------------------
+SINK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint8), C.c_uint64)
+
+
+class PipeOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("out_format", C.c_int32), ("batch_images", C.c_int32),
+                ("scan_threads", C.c_int32), ("slots", C.c_int32), ("sink_threads", C.c_int32),
+                ("sink", SINK_FN), ("sink_user", C.c_void_p)]
+
+
+class PipeStats(C.Structure):
+    _fields_ = [("wall_s", C.c_double), ("scan_s", C.c_double), ("create_s", C.c_double), ("upload_s", C.c_double),
+                ("exec_s", C.c_double), ("download_s", C.c_double), ("sink_s", C.c_double),
+                ("n_inputs", C.c_uint64), ("n_decoded", C.c_uint64), ("n_rejected", C.c_uint64),
+                ("n_batches", C.c_uint64), ("n_batch_failures", C.c_uint64),
+                ("pixels", C.c_uint64), ("in_bytes", C.c_uint64), ("ecs_bytes", C.c_uint64), ("out_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_pipe = None
+
+
+def pipe_lib():
+    global _pipe
+    if _pipe is None:
+        if not os.path.exists(LIBPIPE):
+            raise PjdError(f"{LIBPIPE} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        dev_lib(), host_lib()
+        L = C.CDLL(LIBPIPE)
+        L.pjd_pipe_run_files.restype = C.c_int
+        L.pjd_pipe_run_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.POINTER(PipeOpts), C.POINTER(PipeStats)]
+        L.pjd_pipe_run_memory.restype = C.c_int
+        L.pjd_pipe_run_memory.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int,
+                                          C.POINTER(PipeOpts), C.POINTER(PipeStats)]
+        _pipe = L
+    return _pipe
+
+
+def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_images=1024, scan_threads=0, slots=0,
+             sink_threads=0, sink=None, device=0):
+    """Run the pipelined batcher over in-memory JPEGs (`jpegs`: list of bytes) or files (`paths`).
+
+    `sink(index, name, log, status, data)` is called from worker threads with `data` a numpy copy of the
+    picture (or None).  Returns the statistics as a dict."""
+    L = pipe_lib()
+    o = PipeOpts()
+    o.device, o.out_format, o.batch_images = device, out_format, batch_images
+    o.scan_threads, o.slots, o.sink_threads = scan_threads, slots, sink_threads
+
+    def _tramp(user, index, name, log, status, data, length):
+        pic = np.ctypeslib.as_array(data, shape=(length,)).copy() if data and length else None
+        sink(index, name.decode(), log.decode(), status, pic)
+
+    cb = SINK_FN(_tramp) if sink else SINK_FN()
+    o.sink = cb
+    st = PipeStats()
+    if paths is not None:
+        arr = (C.c_char_p * max(len(paths), 1))(*[p.encode() for p in paths])
+        rc = L.pjd_pipe_run_files(arr, len(paths), C.byref(o), C.byref(st))
+    else:
+        n = len(jpegs)
+        keep = [np.frombuffer(j, np.uint8) for j in jpegs]
+        ptrs = (C.c_void_p * max(n, 1))(*[k.ctypes.data for k in keep])
+        lens = (C.c_uint64 * max(n, 1))(*[len(j) for j in jpegs])
+        nm = (C.c_char_p * max(n, 1))(*[(names[i] if names else f"mem{i}.jpg").encode() for i in range(n)])
+        rc = L.pjd_pipe_run_memory(ptrs, lens, nm, n, C.byref(o), C.byref(st))
+    if rc != 0:
+        raise PjdError(f"pipeline failed ({rc})")
+    return st.as_dict()
 
 
 def plan_info(descs, out_format=OUT_RGB8):

@@ -295,3 +295,73 @@ def test_config3_batch_properties(ctx, port):
     for i in (7, 300, 900):
         alone, _ = ctx.decode([scanned[i].desc])
         assert np.array_equal(alone[0], outs[i])
+
+
+# ---- the pipelined batcher (include/pjd_pipeline.h): the reference's producer/consumer pair -------
+def test_pipeline_memory_all_fixtures_match_reference_hashes():
+    """Every fixture (valid, rejected, entropy-error) through libpjdpipe in small batches on 2 GPU slots:
+    same BMP bytes, same messages and same "no picture" cases as the reference's own code produced."""
+    import threading
+    import pjd_amd
+    names = sorted(MANIFEST)
+    jpegs = [golden_bytes(n) for n in names]
+    got, lock = {}, threading.Lock()
+
+    def sink(index, name, log, status, data):
+        with lock:
+            assert index not in got
+            got[index] = (name, log, status, None if data is None else hashlib.sha256(data.tobytes()).hexdigest(), 0 if data is None else len(data))
+
+    st = pjd_amd.pipe_run(jpegs=jpegs, names=[n + ".jpg" for n in names], out_format=pjd_amd.OUT_BMP,
+                          batch_images=7, scan_threads=3, slots=2, sink_threads=3, sink=sink)
+    assert st["n_inputs"] == len(names) and len(got) == len(names)
+    assert st["n_batches"] == (len(names) + 6) // 7 and st["n_batch_failures"] == 0
+    assert st["n_decoded"] == len(VALID) and st["n_rejected"] == len(names) - len(VALID)
+    for i, n in enumerate(names):
+        ent = MANIFEST[n]
+        name, log, status, sha, length = got[i]
+        assert name == n + ".jpg"
+        if ent["rc"] != 0:
+            assert status == -1 and sha is None, n
+            assert log.endswith(f"{n}.jpg: Error - Invalid JPEG\n"), (n, log)
+        else:
+            assert sha == ent["bmp_sha256"] and length == ent["bmp_len"], n
+            assert (status == 0) == bool(ent["huff_ok"]), n
+    assert st["pixels"] == sum(MANIFEST[n]["dims"][0] * MANIFEST[n]["dims"][1] for n in VALID)
+
+
+def test_pipeline_cli_matches_plain_cli(tmp_path):
+    """bin/decoder --pipeline writes the same files as the one-batch-at-a-time CLI."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    names = [n for n in ["ilsvrc_val_00000001", "env_61x45_420_q100_opt", "neg_progressive_64x48", "err_truncated_eoi_444",
+                         "div_rst_420_64x48", "big_640x480_420_q85", "gray_61x45"] if n in MANIFEST]
+    for n in names:
+        shutil.copy(os.path.join(HERE, "golden", n + ".jpg"), tmp_path / (n + ".jpg"))
+    p = subprocess.run([os.path.join(ROOT, "bin", "decoder"), "--pipeline", "--batch", "3", "--slots", "2"]
+                       + [str(tmp_path / (n + ".jpg")) for n in names] + [str(tmp_path / "missing.jpg")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Profiles:" in p.stdout and "missing.jpg: Error - Error opening input file" in p.stdout
+    for n in names:
+        ent = MANIFEST[n]
+        bmp = tmp_path / (n + ".bmp")
+        for line in ent["stdout"].replace("{path}", str(tmp_path / (n + ".jpg"))).splitlines():
+            assert line in p.stdout, line
+        if ent["rc"] != 0:
+            assert not bmp.exists()
+        else:
+            assert hashlib.sha256(bmp.read_bytes()).hexdigest() == ent["bmp_sha256"], n
+
+
+def test_download_packed_equals_download(ctx):
+    import pjd_amd
+    scanned = [_desc(n) for n in VALID[:9]]
+    with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_BMP) as b:
+        b.upload(); b.decode(); b.sync()
+        a, sa = b.download()
+        p, sp = b.download_packed()
+    assert sa == sp
+    for x, y in zip(a, p):
+        assert np.array_equal(x, y)

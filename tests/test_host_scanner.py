@@ -107,6 +107,15 @@ def test_libpjdhost_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_libpjdpipe_exports_every_declared_symbol():
+    names = [n for n in _declared("pjd_pipeline.h") if n not in _declared("pjd.h") and n not in ("pjd_pipe_sink",)]
+    assert "pjd_pipe_run_files" in names and "pjd_pipe_run_memory" in names
+    exp = _exported(pjd_amd.LIBPIPE)
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+    pjd_amd.pipe_lib()             # loads together with libpjd / libpjdhost (no compute call)
+
+
 def test_plan_info_host_only():
     """The planner runs without a device: lanes, data units, routing."""
     descs, keep = [], []
