@@ -61,6 +61,9 @@ int pjd_pipe_run_files(const char *const *paths, int n, const pjd_pipe_opts *opt
 int pjd_pipe_run_memory(const uint8_t *const *data, const uint64_t *len, const char *const *names, int n,
                         const pjd_pipe_opts *opts, pjd_pipe_stats *stats);
 
+/* GPU slots (context, buffer pools, page-locked output buffer) are kept between runs; this frees them. */
+void pjd_pipe_release(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,42 @@ struct Queue {
     }
 };
 
+// What a GPU slot keeps between runs: its context (stream + buffer pools) and its page-locked output buffer.
+// Page-locking ~0.7 GB costs more than decoding a whole batch, so slots are parked here when a run ends and
+// picked up by the next run on the same device; pjd_pipe_release() frees them.
+struct SlotRes {
+    int device = -1;
+    pjd_ctx *ctx = nullptr;
+    uint8_t *pinned = nullptr;
+    uint64_t pinned_cap = 0;
+};
+std::mutex g_slot_m;
+std::vector<SlotRes> g_parked;
+
+SlotRes take_slot(int device)
+{
+    {
+        std::lock_guard<std::mutex> l(g_slot_m);
+        for (size_t k = 0; k < g_parked.size(); k++)
+            if (g_parked[k].device == device) {
+                SlotRes r = g_parked[k];
+                g_parked.erase(g_parked.begin() + k);
+                return r;
+            }
+    }
+    SlotRes r;
+    r.device = device;
+    if (pjd_open(device, &r.ctx) != PJD_OK) r.ctx = nullptr;
+    return r;
+}
+
+void park_slot(const SlotRes &r)
+{
+    if (!r.ctx) { pjd_host_free(r.pinned); return; }
+    std::lock_guard<std::mutex> l(g_slot_m);
+    g_parked.push_back(r);
+}
+
 struct Pipe {
     pjd_pipe_opts o;
     std::vector<Input> in;
@@ -124,10 +160,11 @@ struct Pipe {
 
     void slot_worker()
     {
-        pjd_ctx *ctx = nullptr;
-        if (pjd_open(o.device, &ctx) == PJD_OK) slots_open.fetch_add(1);
-        uint8_t *pinned = nullptr;
-        uint64_t pinned_cap = 0;
+        SlotRes res = take_slot(o.device);
+        pjd_ctx *ctx = res.ctx;
+        if (ctx) slots_open.fetch_add(1);
+        uint8_t *&pinned = res.pinned;
+        uint64_t &pinned_cap = res.pinned_cap;
         std::atomic<int> latch{0};
         int j;
         while (ready.pop(j)) {
@@ -191,8 +228,7 @@ struct Pipe {
             st.n_decoded += decoded; st.n_rejected += rejected;
             st.pixels += pixels; st.ecs_bytes += ecs; st.out_bytes += outb;
         }
-        pjd_host_free(pinned);
-        if (ctx) pjd_close(ctx);
+        park_slot(res);
     }
 
     void sink_worker()
@@ -260,6 +296,13 @@ int run_pipe(Pipe &p, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
 }  // namespace
 
 extern "C" {
+
+void pjd_pipe_release(void)
+{
+    std::lock_guard<std::mutex> l(g_slot_m);
+    for (SlotRes &r : g_parked) { pjd_host_free(r.pinned); if (r.ctx) pjd_close(r.ctx); }
+    g_parked.clear();
+}
 
 int pjd_pipe_run_files(const char *const *paths, int n, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
 {

@@ -362,8 +362,14 @@ def pipe_lib():
         L.pjd_pipe_run_memory.restype = C.c_int
         L.pjd_pipe_run_memory.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int,
                                           C.POINTER(PipeOpts), C.POINTER(PipeStats)]
+        L.pjd_pipe_release.restype = None
         _pipe = L
     return _pipe
+
+
+def pipe_release():
+    if _pipe is not None:
+        _pipe.pjd_pipe_release()
 
 
 def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_images=1024, scan_threads=0, slots=0,
