@@ -4,8 +4,8 @@
 // reference src/decoder_host.cpp:213-350):
 //   create   plan (pjd_plan.cpp) + allocate HBM and pinned staging
 //   upload   one packed H2D copy of the bitstreams + the small work lists
-//   decode   memset(coefficients) -> table build -> Huffman sync / fix / carry / write ->
-//            DC scan -> exact kernel for the images routed to it -> fused IDCT/colour
+//   decode   table build -> one-pass parallel Huffman decode (entry stream) -> DC scan -> fused sparse
+//            IDCT/colour; images routed to the exact kernel: dense scratch -> exact kernel -> dense IDCT/colour
 //   sync     read the status words; any image the parallel decoder flagged is re-decoded by the
 //            exact kernel (on the GPU) and its picture regenerated
 //   download one D2H copy per picture
@@ -121,6 +121,8 @@ struct pjd_batch {
     uint32_t *d_fb_list = nullptr;       // scratch list for fallback images
     PjdDevIdctWg *d_fb_iwgs = nullptr;   // scratch IDCT work list for fallback images
     int32_t *d_status_init = nullptr;
+    uint64_t *d_opstate = nullptr;       // wg_exit + wg_desc + ticket
+    size_t opstate_bytes = 0;
     uint8_t *h_ecs = nullptr;            // pinned staging
     int32_t *h_status = nullptr;         // pinned
     std::vector<uint32_t> iwg_base, iwg_count;   // per image, into plan.iwgs
@@ -276,17 +278,14 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.du_end, P.n_du, tot));
     TRY_RC(dev_alloc(ctx, b->dev.seg_ent, P.segs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.dcv, P.n_du, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.wg_eagg, P.hwgs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.wg_ent_in, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.out, P.out_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.sub_exit, P.subs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.sub_cnt, P.subs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.sub_chk, P.subs.size() * 2 * PJD_NCHK, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.wg_entry, P.hwgs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.wg_exit, P.hwgs.size() * 2, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.wg_agg, P.hwgs.size() * 2, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.wg_du_in, P.hwgs.size(), tot));
+    // wg_exit [2][n_hwg], wg_desc [n_hwg] and the ticket live in one allocation, zeroed before every launch
+    TRY_RC(dev_alloc(ctx, b->d_opstate, P.hwgs.size() * 3 + 2, tot));
+    b->opstate_bytes = (P.hwgs.size() * 3 + 2) * sizeof(uint64_t);
+    b->dev.wg_exit = b->d_opstate;
+    b->dev.wg_desc = b->d_opstate + P.hwgs.size() * 2;
+    b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + P.hwgs.size() * 3);
     TRY_RC(dev_alloc(ctx, b->dev.dc_agg, P.n_dcblk * 4, tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_carry, P.n_dcblk * 4, tot));
     TRY_RC(dev_alloc(ctx, b->dev.stats, 16, tot));
@@ -380,10 +379,8 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     kt.mark("reset");
     if (parallel) {
         pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
-        pjd_launch_huff_sync(s, b->dev);     kt.mark("huff_sync");
-        pjd_launch_huff_fix(s, b->dev);      kt.mark("huff_fix");
-        pjd_launch_huff_carry(s, b->dev);    kt.mark("huff_carry");
-        pjd_launch_huff_write(s, b->dev);    kt.mark("huff_write");
+        HIP_TRY(ctx, hipMemsetAsync(b->d_opstate, 0, b->opstate_bytes, s));
+        pjd_launch_huff_onepass(s, b->dev);  kt.mark("huff_onepass");
         pjd_launch_dc_scan(s, b->dev);       kt.mark("dc_scan");
         pjd_launch_idct_colour_sparse(s, b->dev, b->d_iwgs, (uint32_t)P.iwgs.size());
         kt.mark("idct_colour");
@@ -564,10 +561,6 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
         info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
     }
     info->n_huff_workgroups = P.hwgs.size();
-    if (std::getenv("PJD_DEBUG_STATS"))
-        std::fprintf(stderr, "[pjd stats] setup_cyc %llu round0_cyc %llu rounds_cyc %llu round0_maxiters %llu | realtime(10ns) setup %llu round0 %llu rounds %llu | waves %zu\n",
-                     st[4], st[5], st[6], st[7], st[8], st[9], st[10], P.hwgs.size()),
-        std::fprintf(stderr, "[pjd stats] max wave life(10ns) %llu max round0 %llu waves>0.5ms %llu >0.8ms %llu >1.0ms %llu\n", st[11], st[12], st[13], st[14], st[15]);
     return PJD_OK;
 }
 

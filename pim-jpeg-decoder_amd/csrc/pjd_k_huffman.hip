@@ -1,4 +1,4 @@
-// pjd_k_huffman.hip -- the PARALLEL entropy decoder for gfx950 (v2).
+// pjd_k_huffman.hip -- the PARALLEL entropy decoder for gfx950: one launch, pjd_k_huff_onepass.
 //
 // Huffman decoding is one dependent chain per restart segment; a batch of ImageNet files has
 // ~10^3 chains, a single 4K picture has one.  To fill 256 CUs the bitstream is cut into fixed
@@ -18,21 +18,23 @@
 //   * in a re-sync round a lane restarts from its predecessor's exit state and stops as soon as
 //     its state equals a checkpoint ("bridge"): the usual cost is the synchronisation distance,
 //     not a whole subsequence.  Only a lane that crosses its whole subsequence unmerged hands a
-//     changed exit state on to its successor for the next round.
+//     changed exit state on to its successor for the next round;
+//   * waves of one image are stitched, their data-unit / entry counts scanned, and the final pass
+//     written in the SAME launch: a wave waits only for earlier waves of its own image (published
+//     64-bit words, decoupled look-back), never for the batch (see pjd_k_huff_onepass).
 //
 //   pjd_k_build_tables   raw (offsets, symbols) tables -> two-level decode table: 10-bit first level, one
 //                        64-entry second-level table per 10-bit prefix that holds longer codes
 //                        (semantics of reference generate_codes / get_next_symbol,
 //                        reference src/jpeg_scanner.cpp:438-465)
-//   pjd_k_huff_sync      rounds as above; exit state and data-unit count per subsequence
-//   pjd_k_huff_fix       stitches wave boundaries (overlap lane's guess vs the predecessor wave's
-//                        truth; a mismatching wave is redone) and reduces per-wave unit counts
-//   pjd_k_huff_carry     one wave per image: scan of those counts -> absolute data-unit index
-//   pjd_k_huff_write     final pass from the now-known entry states.  Output is COMPACT: every non-zero
-//                        AC coefficient becomes one 4-byte entry (value << 16 | zigzag slot) in a stream
-//                        whose per-lane offsets are exact prefix sums, so lanes append 16 bytes at a time
-//                        and nothing has to be zero-filled; DC differences go to a dense int16 array
-//                        (pjd_k_dc_* integrates it); du_end[] / seg_ent[] delimit each unit's entries
+//   pjd_k_huff_onepass   A  speculative round + re-sync rounds inside the wave
+//                        B  stitch to the predecessor wave (its exit state vs the entry assumed here)
+//                        C  counts: scan inside the wave, look-back across the image's waves
+//                        D  final pass from the now-known entry states.  Output is COMPACT: every stored
+//                           AC coefficient becomes one 4-byte entry (value << 16 | zigzag slot) in a stream
+//                           whose per-lane offsets are exact prefix sums, so lanes append 16 bytes at a time
+//                           and nothing has to be zero-filled; DC differences go to a dense int16 array
+//                           (pjd_k_dc_* integrates it); du_end[] / seg_ent[] delimit each unit's entries
 //
 // Exactness: a lane that starts from the true state performs exactly the reference's
 // decode_MCU_component (reference src/jpeg_scanner.cpp:467-520).  Anything irregular seen in the
@@ -348,55 +350,6 @@ __device__ __forceinline__ bool wave_rounds(const PjdDevImage &im, const LaneGeo
     return !__any(changed != 0);
 }
 
-__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_sync(PjdDevBatch B)
-{
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
-    const PjdDevHuffWg wg = B.hwgs[w];
-    const PjdDevImage &im = B.images[wg.image];
-    LaneGeom g; uint32_t tpacked; ChkCtx K;
-    const uint64_t tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
-    wave_setup(B, wg, im, g, tpacked, K);
-    const uint64_t tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
-    // round 0: every lane from the start of its own subsequence (the true state at a segment start)
-    uint32_t p = g.start_bit, c = 0, z = 0, ndu = 0, err = 0, D = 0;
-    if (g.valid) decode_span<MODE_SPEC>(pjd_huff_lds, tpacked, im.n_luma, im.dus_per_mcu, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
-    const uint64_t tc2 = __builtin_amdgcn_s_memtime(), tr2 = __builtin_amdgcn_s_memrealtime();
-    WaveState S = { p + g.base_bit, (c << 8) | z, ndu };
-    const uint64_t entry0 = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);       // lane 0: the assumed entry
-    const bool ok = wave_rounds(im, g, tpacked, K, S, g.valid ? 1u : 0u, B.stats, 0);
-    const uint64_t tc3 = __builtin_amdgcn_s_memtime(), tr3 = __builtin_amdgcn_s_memrealtime();
-    {
-        uint32_t mx = D;
-        for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
-        if (t == 0 && B.stats) {
-            atomicAdd(B.stats + 4, tc1 - tc0); atomicAdd(B.stats + 5, tc2 - tc1); atomicAdd(B.stats + 6, tc3 - tc2); atomicAdd(B.stats + 7, (unsigned long long)mx);
-            atomicAdd(B.stats + 8, tr1 - tr0); atomicAdd(B.stats + 9, tr2 - tr1); atomicAdd(B.stats + 10, tr3 - tr2);
-            atomicMax(B.stats + 11, tr3 - tr0); atomicMax(B.stats + 12, tr2 - tr1);
-            // histogram of wave lifetimes in 100 us buckets is too wide for 16 slots: count waves above 0.5 / 0.8 / 1.0 ms
-            if (tr3 - tr0 > 50000) atomicAdd(B.stats + 13, 1ull);
-            if (tr3 - tr0 > 80000) atomicAdd(B.stats + 14, 1ull);
-            if (tr3 - tr0 > 100000) atomicAdd(B.stats + 15, 1ull);
-        }
-    }
-    if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
-    if (g.owned) {
-        B.sub_exit[g.q] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
-        B.sub_cnt[g.q] = S.cnt;
-        // keep the trajectory's checkpoints: a boundary re-stitch (pjd_k_huff_fix) can then bridge
-        // into them instead of repeating the speculative pass
-        uint4 *dst = reinterpret_cast<uint4 *>(B.sub_chk + (size_t)g.q * 2 * PJD_NCHK);
-        for (int h = 0; h < 2; h++) {
-            const uint32_t *src = h ? K.rem : K.state;
-            dst[2 * h] = make_uint4(src[0], src[64], src[128], src[192]);
-            dst[2 * h + 1] = make_uint4(src[256], src[320], src[384], src[448]);
-        }
-    }
-    if (t == 0) {
-        B.wg_entry[w] = g.valid ? entry0 : ~0ull;
-    }
-    if (t == wg.n_sub) B.wg_exit[w] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Segmented combine used for data-unit counts: element = (value, head flag); a head resets.
 __device__ __forceinline__ void seg_combine(uint32_t av, uint32_t af, uint32_t &bv, uint32_t &bf)   // b = a (+) b
@@ -414,105 +367,104 @@ __device__ __forceinline__ void wave_seg_scan(uint32_t &v, uint32_t &f)      // 
     }
 }
 
-__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_fix(PjdDevBatch B)
-{
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
-    const PjdDevHuffWg wg = B.hwgs[w];
-    const PjdDevImage &im = B.images[wg.image];
-    const bool first_is_head = (B.subs[wg.first_sub].seg >> 31) != 0;
-    uint64_t *exit1 = B.wg_exit + B.n_hwg;
-    bool redo = false;
-    uint64_t truth = 0;
-    if (!first_is_head) {
-        truth = B.wg_exit[w - 1];                    // generation 0: written by pjd_k_huff_sync
-        redo = truth != B.wg_entry[w];
-    }
-    uint32_t my_cnt = 0;
-    if (redo) {                                       // wave-uniform: redo this wave from the true entry
-        LaneGeom g; uint32_t tpacked; ChkCtx K;
-        wave_setup(B, wg, im, g, tpacked, K);
-        WaveState S = { 0, 0, 0 };
-        if (g.owned) {
-            const uint64_t e = B.sub_exit[g.q];
-            S.p_img = (uint32_t)e; S.cz = (((uint32_t)(e >> 32) & 255) << 8) | ((uint32_t)(e >> 40) & 255);
-            S.cnt = B.sub_cnt[g.q];
-            const uint4 *src = reinterpret_cast<const uint4 *>(B.sub_chk + (size_t)g.q * 2 * PJD_NCHK);
-            for (int h = 0; h < 2; h++) {
-                uint32_t *dst = h ? K.rem : K.state;
-                const uint4 a = src[2 * h], b = src[2 * h + 1];
-                dst[0] = a.x; dst[64] = a.y; dst[128] = a.z; dst[192] = a.w;
-                dst[256] = b.x; dst[320] = b.y; dst[384] = b.z; dst[448] = b.w;
-            }
-        }
-        if (t == 0) { S.p_img = (uint32_t)truth; S.cz = (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255); S.cnt = 0; }
-        const bool ok = wave_rounds(im, g, tpacked, K, S, t == 0 ? 1u : 0u, B.stats, 2);
-        if (!ok && t == 0) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
-        if (g.owned) {
-            B.sub_exit[g.q] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
-            B.sub_cnt[g.q] = S.cnt;
-            my_cnt = S.cnt;
-        }
-        if (t == 0) B.wg_entry[w] = truth;
-        if (t == wg.n_sub) exit1[w] = pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255);
-    } else {
-        if (t == 0) exit1[w] = B.wg_exit[w];
-        if (t >= 1 && t - 1 < wg.n_sub) my_cnt = B.sub_cnt[wg.first_sub + t - 1];
-    }
-    // per-wave aggregates: data units (absolute index after the last owned lane if a segment starts
-    // inside, else the number of units completed; head flag) and coefficient entries (plain sum)
-    uint32_t v = 0, f = 0, e = 0;
-    if (t >= 1 && t - 1 < wg.n_sub) {
-        const uint32_t sg = B.subs[wg.first_sub + t - 1].seg;
-        v = my_cnt & 0xffffu;
-        e = my_cnt >> 16;
-        if (sg >> 31) { f = 1; v += B.segs[sg & 0x7fffffffu].first_du; }
-    }
-    wave_seg_scan(v, f);
-    for (int off = 32; off; off >>= 1) e += __shfl_xor(e, off);
-    if (t == PJD_HUFF_THREADS - 1) { B.wg_agg[2 * w] = v; B.wg_agg[2 * w + 1] = f; B.wg_eagg[w] = e; }
-}
-
-__global__ __launch_bounds__(64) void pjd_k_huff_carry(PjdDevBatch B)
-{
-    const PjdDevImage &im = B.images[blockIdx.x];
-    const uint32_t lane = threadIdx.x, n = im.n_hwg;
-    uint32_t carry = 0, ecarry = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t j = base + lane;
-        uint32_t v = 0, f = 0, e = 0;
-        if (j < n) { v = B.wg_agg[2 * (im.hwg_base + j)]; f = B.wg_agg[2 * (im.hwg_base + j) + 1]; e = B.wg_eagg[im.hwg_base + j]; }
-        wave_seg_scan(v, f);
-        const uint32_t pv = __shfl_up(v, 1), pf = __shfl_up(f, 1);
-        uint32_t in = carry;
-        if (lane > 0) in = pf ? pv : carry + pv;
-        uint32_t es = e;                                        // inclusive scan of entries
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(es, off); if ((int)lane >= off) es += o; }
-        if (j < n) { B.wg_du_in[im.hwg_base + j] = in; B.wg_ent_in[im.hwg_base + j] = ecarry + es - e; }
-        const uint32_t lv = __shfl(v, 63), lf = __shfl(f, 63);
-        carry = lf ? lv : carry + lv;
-        ecarry += __shfl(es, 63);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch B)
+// The kernel.  Synchronise, stitch, scan and write in a single launch.
+//
+// With one launch per stage every stage waits for the slowest wave of the whole batch, and that wave is
+// slow by nature: somewhere in 10^5 subsequences there is a stretch of a few KB on which speculative
+// decoders do not fall into step, and it can only be walked sequentially (measured on the 1024-image
+// batch: mean wave 0.63 ms, slowest 1.38 ms in stage A).  Here a wave depends only on waves of its OWN
+// image that precede it, so everything else proceeds to the write pass while the stragglers finish
+// (four launches 2.31 ms -> one launch 1.78 ms on that batch):
+//
+//   * waves take their index from a ticket counter, so every wave a wave waits for has already started
+//     (waits can always be satisfied; they are bounded anyway and poison the image on time-out);
+//   * a wave publishes its speculative exit state (generation 0); its successor compares that with the
+//     entry it assumed, re-bridges from the truth if they differ, and publishes generation 1 -- two hops,
+//     never a chain across the image; at the very end it checks that the entry it used is what its
+//     predecessor finally produced (else: exact kernel);
+//   * data-unit counts (segmented: a restart segment's first subsequence resets to the segment's first
+//     unit) and entry counts are combined with a decoupled look-back over the image's waves, 64
+//     descriptors per step;
+//   * the write pass runs from registers; tables and checkpoints are still in LDS.
+// All published words are self-contained 64-bit values (state or descriptor + flag bits), so relaxed
+// agent-scope atomics are enough.  wg_exit / wg_desc / ticket are zeroed before every launch.
+#define OP_FLAG        (1ull << 63)
+#define OP_ST_AGG      (1ull << 62)            // descriptor holds this wave's aggregate
+#define OP_ST_PFX      (2ull << 62)            // descriptor holds the inclusive prefix up to this wave
+#define OP_ST_MASK     (3ull << 62)
+#define OP_POISON      (1ull << 61)
+#define OP_HEAD        (1ull << 60)
+#define OP_SPIN_LIMIT  (1u << 22)
+
+__device__ __forceinline__ uint64_t op_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void op_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ uint64_t op_desc(uint64_t status, uint32_t v, uint32_t f, uint32_t e, bool poison)
 {
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    return status | (poison ? OP_POISON : 0ull) | (f ? OP_HEAD : 0ull) | ((uint64_t)(v & 0x0fffffffu) << 32) | e;
+}
+
+// lane 0 waits for a flagged word; the value (flag stripped) is returned to every lane
+__device__ __forceinline__ uint64_t op_wait_flag(const uint64_t *p, bool &timeout)
+{
+    uint64_t v = 0;
+    if (threadIdx.x == 0)
+        for (uint32_t it = 0; it < OP_SPIN_LIMIT; it++) {
+            v = op_load(p);
+            if (v & OP_FLAG) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    v = ((uint64_t)hi << 32) | lo;
+    timeout = timeout || !(v & OP_FLAG);
+    return v & ~OP_FLAG;
+}
+
+__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBatch B)
+{
+    const uint32_t t = threadIdx.x;
+    uint32_t w = 0;
+    if (t == 0) w = atomicAdd(B.ticket, 1u);
+    w = __builtin_amdgcn_readfirstlane(w);
     const PjdDevHuffWg wg = B.hwgs[w];
     const PjdDevImage &im = B.images[wg.image];
+    uint64_t *exit0 = B.wg_exit, *exit1 = B.wg_exit + B.n_hwg;
     LaneGeom g; uint32_t tpacked; ChkCtx K;
     wave_setup(B, wg, im, g, tpacked, K);
     const uint32_t nl = im.n_luma, dus = im.dus_per_mcu;
     const bool first_is_head = (B.subs[wg.first_sub].seg >> 31) != 0;
+    bool dead = false;                                   // wave-uniform: a wait timed out or a predecessor is poisoned
     uint32_t flag = 0;
-    // the entry this wave was synchronised with must be what its predecessor finally produced
-    if (t == 0 && !first_is_head && B.wg_entry[w] != B.wg_exit[B.n_hwg + w - 1]) flag = 1;
 
-    // absolute data-unit index and entry index at the entry of every owned lane
+    // ---- A: speculative round + re-sync rounds inside the wave
+    WaveState S;
+    {
+        uint32_t p = g.start_bit, c = 0, z = 0, ndu = 0, err = 0, D = 0;
+        if (g.valid) decode_span<MODE_SPEC>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
+        S.p_img = p + g.base_bit; S.cz = (c << 8) | z; S.cnt = ndu;
+    }
+    const uint64_t entry0 = pjd_pack_state(__shfl(S.p_img, 0), __shfl(S.cz, 0) >> 8, __shfl(S.cz, 0) & 255);   // lane 0: the assumed entry
+    bool ok = wave_rounds(im, g, tpacked, K, S, g.valid ? 1u : 0u, B.stats, 0);
+    if (t == wg.n_sub) op_store(exit0 + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
+
+    // ---- B: stitch to the predecessor wave: redo this wave's bridges from the true entry if the guess was wrong
+    uint64_t entry_used = entry0;
+    if (!first_is_head) {
+        const uint64_t truth = op_wait_flag(exit0 + w - 1, dead);
+        if (!dead && truth != entry0) {
+            if (t == 0) { S.p_img = (uint32_t)truth; S.cz = (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255); S.cnt = 0; }
+            ok = wave_rounds(im, g, tpacked, K, S, t == 0 ? 1u : 0u, B.stats, 2) && ok;
+            entry_used = truth;
+        }
+    }
+    if (t == wg.n_sub) op_store(exit1 + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
+    if (!ok) flag = 1;
+
+    // ---- C: counts.  Inside the wave: segmented scan of data units, plain scan of entries ...
     uint32_t cnt = 0, ecnt = 0, v = 0, f = 0, seg_first_du = 0, seg_n_du = 0;
     if (g.owned) {
-        const uint32_t packed = B.sub_cnt[g.q];
-        cnt = packed & 0xffffu; ecnt = packed >> 16;
+        cnt = S.cnt & 0xffffu; ecnt = S.cnt >> 16;
         const PjdDevSegment sg = B.segs[g.seg];
         seg_first_du = sg.first_du; seg_n_du = sg.n_du;
         v = cnt;
@@ -521,15 +473,60 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
     wave_seg_scan(v, f);
     uint32_t es = ecnt;
     for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(es, off); if ((int)t >= off) es += o; }
-    if (g.owned) {
-        const uint32_t D_out = f ? v : B.wg_du_in[w] + v;
+    const uint32_t agg_v = __shfl(v, 63), agg_f = __shfl(f, 63), agg_e = __shfl(es, 63);
+    // ... across the image's waves: decoupled look-back
+    uint32_t du_in = 0, ent_in = 0;
+    if (w == im.hwg_base) {
+        if (t == 0) op_store(B.wg_desc + w, op_desc(OP_ST_PFX, agg_v, agg_f, agg_e, dead));
+    } else {
+        if (t == 0) op_store(B.wg_desc + w, op_desc(OP_ST_AGG, agg_v, agg_f, agg_e, dead));
+        uint32_t rv = 0, rf = 0, re = 0;                  // combination of the descriptors gathered so far (identity)
+        bool poison = false;
+        int hi = (int)w - 1;
+        for (;;) {
+            const int j = hi - (int)t;
+            const bool inside = j >= (int)im.hwg_base;
+            uint64_t d = OP_ST_PFX;                        // before the image's first wave: an empty prefix
+            if (inside) {
+                uint32_t it = 0;
+                do { d = op_load(B.wg_desc + j); if (d & OP_ST_MASK) break; __builtin_amdgcn_s_sleep(8); } while (++it < OP_SPIN_LIMIT);
+            }
+            const bool ready = (d & OP_ST_MASK) != 0;
+            if (__any(!ready)) { dead = true; break; }
+            const uint64_t pfx_mask = __ballot((d & OP_ST_MASK) == OP_ST_PFX);   // never empty past the image start
+            const int k = pfx_mask ? __builtin_ctzll(pfx_mask) : 64;              // nearest lane holding a prefix
+            const bool use = (int)t <= k;
+            uint32_t xv = use ? (uint32_t)(d >> 32) & 0x0fffffffu : 0u, xf = use ? (uint32_t)((d >> 60) & 1u) : 0u, xe = use ? (uint32_t)d : 0u;
+            poison = poison || __any(use && (d & OP_POISON));
+            // lane l holds wave hi-l: larger l = earlier.  Suffix-combine so that lane 0 = X_k (+) ... (+) X_0.
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t ov = __shfl_down(xv, off), of = __shfl_down(xf, off), oe = __shfl_down(xe, off);
+                if ((int)t + off < 64) { seg_combine(ov, of, xv, xf); xe += oe; }
+            }
+            const uint32_t wv = __shfl(xv, 0), wf = __shfl(xf, 0), we = __shfl(xe, 0);
+            // running = window (+) running
+            { uint32_t nv = rv, nf = rf; seg_combine(wv, wf, nv, nf); rv = nv; rf = nf; re += we; }
+            if (k < 64) break;
+            hi -= 64;
+        }
+        if (poison) dead = true;
+        du_in = rv; ent_in = re;                           // rf set: rv is an absolute index; else a count from the image's first unit (same thing)
+        uint32_t iv = agg_v, ifl = agg_f;
+        seg_combine(rv, rf, iv, ifl);
+        if (t == 0) op_store(B.wg_desc + w, op_desc(OP_ST_PFX, iv, ifl, re + agg_e, dead));
+    }
+
+    // ---- D: final pass from the true entry states
+    const uint32_t prev_p = __shfl_up(S.p_img, 1), prev_cz = __shfl_up(S.cz, 1);
+    if (g.owned && !dead) {
+        const uint32_t D_out = f ? v : du_in + v;
         uint32_t D = D_out - cnt;
         const uint32_t D_in = D, D_end = seg_first_du + seg_n_du;
         uint32_t p, c, z;
         if (g.seg_first) { p = g.start_bit; c = 0; z = 0; }
         else {
-            const uint64_t e = (t == 1) ? B.wg_entry[w] : B.sub_exit[g.q - 1];
-            p = (uint32_t)e - g.base_bit; c = (uint32_t)(e >> 32) & 255; z = (uint32_t)(e >> 40) & 255;
+            if (t == 1) { p = (uint32_t)entry_used - g.base_bit; c = (uint32_t)(entry_used >> 32) & 255; z = (uint32_t)(entry_used >> 40) & 255; }
+            else { p = prev_p - g.base_bit; c = prev_cz >> 8; z = prev_cz & 255; }
             if (D_in < D_end && (D_in % dus) != c) flag = 1;          // phase must agree with the count
         }
         uint32_t ndu = 0, err = 0;
@@ -537,27 +534,29 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_write(PjdDevBatch
         O.ent = B.ent + im.ent_base;
         O.du_end = B.du_end + im.du_base;
         O.dcv = B.dcv + im.du_base;
-        O.epos = O.epos0 = B.wg_ent_in[w] + es - ecnt;
+        O.epos = O.epos0 = ent_in + es - ecnt;
         O.acc = make_uint4(0, 0, 0, 0);
         if (g.seg_first) B.seg_ent[g.seg] = O.epos;
         if (D_in < D_end) {
             decode_span<MODE_WRITE>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, &O, D, D_end);
             if (err) flag = 1;
             if (D == D_end) {
-                // this lane completed the segment: the reference's BitReader must be able to reach
-                // the next segment by align() alone, and must not have read past the data
                 if (p > g.seg_end_bit) flag = 1;
                 const bool has_next = g.seg + 1 < im.seg_base + im.n_seg;
                 if (has_next && ((p + 7) & ~7u) != g.seg_end_bit) flag = 1;
             } else {
-                // stopped at the subsequence end: must reproduce the synchronised exit state and counts
-                const uint64_t e = B.sub_exit[g.q];
-                if ((uint32_t)e - g.base_bit != p || ((uint32_t)(e >> 32) & 255) != c || ((uint32_t)(e >> 40) & 255) != z) flag = 1;
-                if (ndu != B.sub_cnt[g.q]) flag = 1;
-                if (g.seg_last) flag = 1;                              // data ended before all units were decoded
+                if (S.p_img - g.base_bit != p || (S.cz >> 8) != c || (S.cz & 255) != z) flag = 1;
+                if (ndu != S.cnt) flag = 1;
+                if (g.seg_last) flag = 1;
             }
         }
     }
+    // the entry this wave was synchronised with must be what its predecessor finally produced
+    if (!first_is_head && !dead) {
+        const uint64_t fin = op_wait_flag(exit1 + w - 1, dead);
+        if (fin != entry_used) flag = 1;
+    }
+    if (dead) flag = 1;
     if (flag) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
 }
 
@@ -569,19 +568,7 @@ void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
     if (b.n_images == 0) return;
     hipLaunchKernelGGL(pjd_k_build_tables, dim3(b.n_images * PJD_MAX_TABLES), dim3(256), 0, s, b);
 }
-void pjd_launch_huff_sync(hipStream_t s, const PjdDevBatch &b)
+void pjd_launch_huff_onepass(hipStream_t s, const PjdDevBatch &b)
 {
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_sync, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
-}
-void pjd_launch_huff_fix(hipStream_t s, const PjdDevBatch &b)
-{
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_fix, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
-}
-void pjd_launch_huff_carry(hipStream_t s, const PjdDevBatch &b)
-{
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_carry, dim3(b.n_images), dim3(64), 0, s, b);
-}
-void pjd_launch_huff_write(hipStream_t s, const PjdDevBatch &b)
-{
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_write, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
+    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_onepass, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
 }

@@ -23,16 +23,10 @@ struct PjdDevBatch {
     int16_t *dcv;                        // per data unit: DC difference, integrated in place by pjd_k_dc_*
     uint8_t *out;
     int32_t *status;                     // per image
-    // Huffman synchronisation scratch
-    uint64_t *sub_exit;                  // per subsequence: packed state at its end
-    uint32_t *sub_cnt;                   // per subsequence: data units completed inside it
-    uint32_t *sub_chk;                   // per subsequence: PJD_NCHK checkpoint states + PJD_NCHK "units still to come"
-    uint64_t *wg_entry;                  // per Huffman workgroup: entry state it assumed for its first owned subsequence
-    uint64_t *wg_exit;                   // [2][n_hwg]: exit state of its last owned subsequence, generation 0/1
-    uint32_t *wg_agg;                    // per Huffman workgroup: {value, has_head}
-    uint32_t *wg_du_in;                  // per Huffman workgroup: absolute data-unit index at its entry
-    uint32_t *wg_eagg;                   // per Huffman workgroup: entries its subsequences produce
-    uint32_t *wg_ent_in;                 // per Huffman workgroup: entry index (image-relative) at its entry
+    // Huffman one-pass scratch (zeroed before every launch)
+    uint64_t *wg_exit;                   // [2][n_hwg]: exit state of a wave's last owned subsequence | flag; generation 0 / 1
+    uint64_t *wg_desc;                   // per Huffman workgroup: look-back descriptor (status | poison | head | units | entries)
+    uint32_t *ticket;                    // wave index dispenser
     // DC prediction scratch
     uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
     uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
@@ -51,7 +45,4 @@ void pjd_launch_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernel
 // ---- entropy decode (pjd_k_huffman.hip) -----------------------------------------
 void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, uint32_t n);
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
-void pjd_launch_huff_sync(hipStream_t s, const PjdDevBatch &b);
-void pjd_launch_huff_fix(hipStream_t s, const PjdDevBatch &b);
-void pjd_launch_huff_carry(hipStream_t s, const PjdDevBatch &b);
-void pjd_launch_huff_write(hipStream_t s, const PjdDevBatch &b);
+void pjd_launch_huff_onepass(hipStream_t s, const PjdDevBatch &b);   // synchronise + stitch + scan + write

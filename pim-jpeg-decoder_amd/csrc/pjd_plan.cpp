@@ -165,6 +165,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         const bool luma11 = (g.hs == 1 && g.vs == 1);
         const bool std_rule = (d.flags & PJD_F_STANDARD_RESTART) != 0;
         bool sequential = (d.flags & PJD_F_FORCE_SEQUENTIAL) != 0 || !tables_parallel_ok;
+        if (g.n_du >= (1u << 28)) sequential = true;      // look-back descriptors carry 28-bit unit indices
         uint32_t nseg_total = 1;
         if (RI != 0) {
             nseg_total = (g.n_mcu + RI - 1) / RI;
