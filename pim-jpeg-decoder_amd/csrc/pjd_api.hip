@@ -286,6 +286,8 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     b->dev.wg_exit = b->d_opstate;
     b->dev.wg_desc = b->d_opstate + P.hwgs.size() * 2;
     b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + P.hwgs.size() * 3);
+    b->dev.dbg = nullptr;
+    if (std::getenv("PJD_DEBUG_STATS")) TRY_RC(dev_alloc(ctx, b->dev.dbg, P.hwgs.size() * 32, tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_agg, P.n_dcblk * 4, tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_carry, P.n_dcblk * 4, tot));
     TRY_RC(dev_alloc(ctx, b->dev.stats, 16, tot));
@@ -339,8 +341,13 @@ struct KernelTimer {
     hipStream_t s;
     std::vector<hipEvent_t> ev;
     std::vector<std::string> names;
+    bool debug_sync = std::getenv("PJD_DEBUG_SYNC") != nullptr;
     void mark(const char *name)
     {
+        if (debug_sync) {                                  // PJD_DEBUG_SYNC=1: name the launch a fault belongs to
+            const hipError_t e = hipStreamSynchronize(s);
+            std::fprintf(stderr, "[pjd] %-14s %s\n", name, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        }
         if (!t) return;
         hipEvent_t e;
         hipEventCreate(&e);
@@ -376,6 +383,7 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     kt.mark("start");
     HIP_TRY(ctx, hipMemcpyAsync(b->dev.status, b->d_status_init, sizeof(int32_t) * P.images.size(), hipMemcpyDeviceToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(b->dev.stats, 0, 16 * sizeof(unsigned long long), s));
+    if (b->dev.dbg) HIP_TRY(ctx, hipMemsetAsync(b->dev.dbg, 0, P.hwgs.size() * 32 * sizeof(uint32_t), s));
     kt.mark("reset");
     if (parallel) {
         pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
@@ -561,6 +569,34 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
         info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
     }
     info->n_huff_workgroups = P.hwgs.size();
+    if (b->dev.dbg && b->decoded) {          // PJD_DEBUG_STATS: wave timeline of the last decode (units of 10 ns)
+        std::vector<uint32_t> d(P.hwgs.size() * 32);
+        if (hipMemcpy(d.data(), b->dev.dbg, d.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && !P.hwgs.empty()) {
+            uint32_t t0 = d[0];
+            for (size_t k = 0; k < P.hwgs.size(); k++) if ((int32_t)(d[k * 32] - t0) < 0) t0 = d[k * 32];
+            double sum[6] = {0}; uint32_t mx[6] = {0}; size_t worst = 0; uint32_t worst_end = 0;
+            for (size_t k = 0; k < P.hwgs.size(); k++) {
+                const uint32_t *e = &d[k * 32];
+                uint32_t end = e[0] - t0;
+                for (int q = 1; q <= 5; q++) { sum[q] += e[q]; if (e[q] > mx[q]) mx[q] = e[q]; end += e[q]; }
+                sum[0] += e[0] - t0; if (e[0] - t0 > mx[0]) mx[0] = e[0] - t0;
+                if (end > worst_end) { worst_end = end; worst = k; }
+            }
+            const double n = (double)P.hwgs.size();
+            std::fprintf(stderr, "[pjd waves] n %zu | mean(us): start %.1f round0 %.1f roundsA %.1f stitch %.1f scan %.1f write+verify %.1f | max(us): %.1f %.1f %.1f %.1f %.1f %.1f\n",
+                         P.hwgs.size(), sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, sum[4] / n / 100, sum[5] / n / 100,
+                         mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0, mx[4] / 100.0, mx[5] / 100.0);
+            const uint32_t *e = &d[worst * 32];
+            std::fprintf(stderr, "[pjd waves] last to finish: wave %zu (image %u, %u subs) start %.1f round0 %.1f roundsA %.1f stitch %.1f scan %.1f write %.1f -> end %.1f us\n",
+                         worst, e[6], e[7], (e[0] - t0) / 100.0, e[1] / 100.0, e[2] / 100.0, e[3] / 100.0, e[4] / 100.0, e[5] / 100.0, worst_end / 100.0);
+            // the waves of that image
+            for (size_t k = 0; k < P.hwgs.size(); k++)
+                if (d[k * 32 + 6] == e[6])
+                    std::fprintf(stderr, "[pjd waves]   wave %zu: start %.1f round0 %.1f roundsA %.1f stitch %.1f scan %.1f write %.1f\n", k,
+                                 (d[k * 32] - t0) / 100.0, d[k * 32 + 1] / 100.0, d[k * 32 + 2] / 100.0, d[k * 32 + 3] / 100.0, d[k * 32 + 4] / 100.0, d[k * 32 + 5] / 100.0),
+                    [&] { std::fprintf(stderr, "[pjd waves]     rounds (lanes:us):"); for (int r = 0; r < 24 && d[k * 32 + 8 + r]; r++) std::fprintf(stderr, " %u:%.1f", d[k * 32 + 8 + r] >> 24, (d[k * 32 + 8 + r] & 0xffffff) / 100.0); std::fprintf(stderr, "\n"); }();
+        }
+    }
     return PJD_OK;
 }
 

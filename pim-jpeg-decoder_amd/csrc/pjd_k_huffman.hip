@@ -159,18 +159,30 @@ struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided b
     uint32_t chk_bits;     // checkpoint spacing
 };
 
+struct ChkCursor { uint32_t j, next_chk; };      // next checkpoint of the pass in progress
+
+enum { SPAN_END = 0, SPAN_MERGED = 1, SPAN_YIELDED = 2 };
+
+// After a SPEC / BRIDGE pass: checkpoints (re)written in it hold "units so far"; make them "units still to come".
+__device__ __forceinline__ void chk_finish(const ChkCtx &K, uint32_t j, uint32_t ndu)
+{
+    for (uint32_t i = 1; i < j; i++) K.rem[i * 64] = ndu - K.rem[i * 64];
+}
+
 // Decodes symbols that START before end_bit.  State (p, c, z): bit position relative to base16,
-// data-unit phase within the MCU, zigzag slot (0 = DC expected).  Returns true when a BRIDGE pass
-// merged into the recorded trajectory (then ndu already includes the units still to come).
+// data-unit phase within the MCU, zigzag slot (0 = DC expected).  Returns SPAN_MERGED when a BRIDGE pass
+// merged into the recorded trajectory (then ndu already includes the units still to come), SPAN_YIELDED
+// when a BRIDGE pass stopped because at most `yield_lanes` lanes of the wave were still decoding (the
+// caller continues those with the wave-cooperative decoder), else SPAN_END.
 template <int MODE>
-__device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacked, uint32_t nl, uint32_t dus,
-                                            const uint4 *base16, uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
-                                            uint32_t &ndu, uint32_t &err, const ChkCtx &K,
-                                            OutCtx *O, uint32_t &D, uint32_t D_end)
+__device__ __forceinline__ int decode_span(const uint8_t *tabs, uint32_t tpacked, uint32_t nl, uint32_t dus,
+                                           const uint4 *base16, uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
+                                           uint32_t &ndu, uint32_t &err, const ChkCtx &K, ChkCursor &cur, uint32_t yield_lanes,
+                                           OutCtx *O, uint32_t &D, uint32_t D_end)
 {
     // `ndu` is a packed counter: data units completed in the low 16 bits, AC entries produced in the
     // high 16 bits (both fit for a subsequence of <= 1024 bytes)
-    if (p >= end_bit) return false;
+    if (p >= end_bit) return SPAN_END;
     // wave-uniform image constants: as scalars they are waited for HERE; left in vector registers their
     // first use sits inside the loop and drags a vmcnt(0) -- i.e. a wait for the stream prefetch -- into
     // every iteration
@@ -179,12 +191,13 @@ __device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacke
     tpacked = __builtin_amdgcn_readfirstlane(tpacked);
     BitWin w;
     w.init(base16, p);
-    uint32_t j = 1, next_chk = K.start_bit + K.chk_bits;
-    bool merged = false;
+    uint32_t j = cur.j, next_chk = cur.next_chk;
+    int res = SPAN_END;
     while (p < end_bit && (MODE != MODE_WRITE || D < D_end)) {
+        if (MODE == MODE_BRIDGE && yield_lanes && (uint32_t)__popcll(__ballot(true)) <= yield_lanes) { res = SPAN_YIELDED; break; }
         if (MODE != MODE_WRITE && p >= next_chk) {
             const uint32_t st = ((p - K.start_bit) << 12) | (c << 8) | z;      // p-start < 2^14, c < 16, z < 64
-            if (MODE == MODE_BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; merged = true; break; }
+            if (MODE == MODE_BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
             K.state[j * 64] = st;
             K.rem[j * 64] = ndu;                                                // turned into "still to come" after the pass
             j++;
@@ -248,11 +261,8 @@ __device__ __forceinline__ bool decode_span(const uint8_t *tabs, uint32_t tpacke
         if (pend >= 2) O->ent[O->epos - 2] = O->acc.z;
         if (pend >= 3) O->ent[O->epos - 3] = O->acc.y;
     }
-    if (MODE != MODE_WRITE) {
-        // checkpoints (re)written in this pass hold "units so far"; make them "units still to come"
-        for (uint32_t i = 1; i < j; i++) K.rem[i * 64] = ndu - K.rem[i * 64];
-    }
-    return merged;
+    cur.j = j; cur.next_chk = next_chk;
+    return res;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,7 +278,7 @@ struct LaneGeom {
     const uint4 *base16;           // the lane's own origin: its subsequence start rounded down to 16 bytes
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][chk_state 8x64 u32][chk_rem 8x64 u32]
+extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][chk_state 8x64 u32][chk_rem 8x64 u32][staged subsequence]
 
 __device__ __forceinline__ void wave_setup(const PjdDevBatch &B, const PjdDevHuffWg &wg, const PjdDevImage &im,
                                            LaneGeom &g, uint32_t &tpacked, ChkCtx &K)
@@ -322,26 +332,158 @@ __device__ __forceinline__ void wave_setup(const PjdDevBatch &B, const PjdDevHuf
     __syncthreads();          // one wave: a wait on the LDS stores
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative BRIDGE pass: the whole wave decodes ONE subsequence.
+//
+// After the first re-sync round only a few lanes of a wave still have work, and what they have is the
+// worst kind: stretches on which the speculative trajectory never falls into step, so a lane walks a whole
+// subsequence alone at ~580 cycles per symbol -- the chains that decide how long the slowest wave lives.
+// Here the 64 lanes decode the AC symbol that WOULD start at each of the next 64 bit positions (one
+// table look-up each, in parallel), and scalar code then follows the real chain through those candidates
+// with v_readlane: ~10 scalar instructions per symbol instead of a ~70-instruction vector iteration.
+// A window ends at the end of a data unit (the next unit may use other tables), after 64 bits, at the
+// subsequence end or when the pass merges into a checkpoint.  Semantics are those of
+// decode_span<MODE_BRIDGE>, symbol for symbol; every argument is wave-uniform.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t coop_lookup(const uint8_t *tabs, uint32_t slot, uint32_t bits)
+{
+    uint32_t e = *reinterpret_cast<const uint16_t *>(tabs + slot * PJD_L1_BYTES + 2 * (bits >> (32 - PJD_LUT_BITS)));
+    if (e & 0x8000u) e = *reinterpret_cast<const uint16_t *>(tabs + 2 * ((e & 0x7fffu) + ((bits >> 16) & 63u)));
+    return e;
+}
+
+__device__ __forceinline__ int coop_bridge(const uint8_t *tabs, uint32_t tpacked, uint32_t nl, uint32_t dus,
+                                           const uint4 *base16, uint32_t sub_bytes, uint32_t &p_io, uint32_t &c_io, uint32_t &z_io,
+                                           uint32_t end_bit, uint32_t &ndu_io, uint32_t *chk_state, uint32_t *chk_rem,
+                                           uint32_t start_bit, uint32_t chk_bits, uint32_t j, uint32_t next_chk, uint32_t *stream)
+{
+    const uint32_t t = threadIdx.x;
+    // the subsequence (it starts < 16 bytes after base16) + look-ahead, as big-endian words in LDS
+    const uint32_t n16 = (sub_bytes + 16 + 64) / 16;
+    for (uint32_t i = t; i < n16; i += PJD_HUFF_THREADS) {
+        uint4 v = base16[i];
+        v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+        reinterpret_cast<uint4 *>(stream)[i] = v;
+    }
+    __syncthreads();
+    uint32_t p = p_io, c = c_io, z = z_io, ndu = ndu_io;
+    int res = SPAN_END;
+    for (;;) {
+        // ---- candidates: AC symbol at every bit offset p + t; DC symbol at p
+        const uint32_t comp = (c >= nl ? 1u : 0u) + (c > nl ? 1u : 0u);
+        const uint32_t dc_slot = (tpacked >> (8 * comp)) & 15u, ac_slot = (tpacked >> (8 * comp + 4)) & 15u;
+        const uint32_t bp = p + t;
+        const uint32_t w0 = stream[bp >> 5], w1 = stream[(bp >> 5) + 1];
+        const uint32_t bits = (uint32_t)((((uint64_t)w0 << 32) | w1) << (bp & 31) >> 32);
+        const uint32_t e = coop_lookup(tabs, ac_slot, bits);
+        const uint32_t sym = e & 255u, size = sym & 15u;
+        const uint32_t pack = (((e >> 8) & 31u) + size) | ((sym >> 4) << 8) | (size ? 0x1000u : 0u) | (sym == 0 ? 0x2000u : 0u);
+        uint32_t dc_used = 0;
+        if (z == 0) {
+            const uint32_t bits0 = __builtin_amdgcn_readlane(bits, 0);
+            const uint32_t ed = coop_lookup(tabs, dc_slot, bits0);
+            dc_used = __builtin_amdgcn_readfirstlane(((ed >> 8) & 31u) + (ed & 15u));
+        }
+        // ---- follow the chain through the window
+        uint32_t pos = 0;
+        bool stop = false;
+        for (;;) {
+            const uint32_t q = p + pos;
+            if (q >= end_bit) { stop = true; break; }
+            if (q >= next_chk) {
+                const uint32_t st = ((q - start_bit) << 12) | (c << 8) | z;
+                const uint32_t old = __builtin_amdgcn_readfirstlane(chk_state[j * 64]);
+                if (old == st) { ndu += __builtin_amdgcn_readfirstlane(chk_rem[j * 64]); res = SPAN_MERGED; stop = true; break; }
+                if (t == 0) { chk_state[j * 64] = st; chk_rem[j * 64] = ndu; }
+                j++;
+                next_chk += chk_bits;
+            }
+            if (z == 0) {                          // DC: only the candidate at the window start exists
+                if (pos != 0) break;
+                pos = dc_used;
+                z = 1;
+                continue;
+            }
+            if (pos >= 64) break;
+            const uint32_t s = __builtin_amdgcn_readlane(pack, pos);
+            const uint32_t zr = z + ((s >> 8) & 15u);
+            const bool eob = (s & 0x2000u) != 0, over = zr > 63;
+            const bool store = !eob && !over && ((s & 0x1000u) != 0 || zr == 52);
+            const bool done = eob || over || zr == 63;
+            ndu += (done ? 1u : 0u) + (store ? 0x10000u : 0u);
+            pos += s & 63u;
+            if (done) { z = 0; c = (c + 1 == dus) ? 0u : c + 1; break; }
+            z = zr + 1;
+        }
+        p += pos;
+        if (stop) break;
+    }
+    if (t == 0) for (uint32_t i = 1; i < j; i++) chk_rem[i * 64] = ndu - chk_rem[i * 64];
+    p_io = p; c_io = c; z_io = z; ndu_io = ndu;
+    return res;
+}
+
+// A re-sync round that STARTS with at most PJD_COOP_START_LANES active lanes is done cooperatively, one lane after
+// the other; a round in lane-parallel mode hands over when only PJD_COOP_YIELD_LANES lanes are still decoding.
+// Measured (MI355X): a cooperative pass over a 512-byte subsequence takes ~56 us against ~190 us for a lone lane
+// and ~300 us for a lane-parallel round, but passes are serial, so anything above ONE lane loses (1024-image
+// batch, start/yield 1/1: 1.75 ms, 4/1: 2.08, 8/1: 2.24, 16/1: 2.68; single 4K picture 1.16 / 1.39 / 1.82 / 2.16,
+// 1.30 ms without the cooperative pass).
+#ifndef PJD_COOP_START_LANES
+#define PJD_COOP_START_LANES 1
+#endif
+#ifndef PJD_COOP_YIELD_LANES
+#define PJD_COOP_YIELD_LANES 1
+#endif
+
 // Lanes have different origins, so states are exchanged as bit positions relative to the image's ecs.
 struct WaveState { uint32_t p_img, cz, cnt; };
 
-__device__ __forceinline__ bool wave_rounds(const PjdDevImage &im, const LaneGeom &g, uint32_t tpacked,
-                                            const ChkCtx &K, WaveState &S, uint32_t changed, unsigned long long *stats, int stat_base)
+__device__ __forceinline__ bool wave_rounds(const PjdDevBatch &B, const PjdDevImage &im, const LaneGeom &g, uint32_t tpacked,
+                                            const ChkCtx &K, WaveState &S, uint32_t changed, unsigned long long *stats, int stat_base, uint32_t *rdbg = nullptr)
 {
     const uint8_t *tabs = pjd_huff_lds;
-    const uint32_t nl = im.n_luma, dus = im.dus_per_mcu;
+    const uint32_t t = threadIdx.x;
+    const uint32_t nl = __builtin_amdgcn_readfirstlane(im.n_luma), dus = __builtin_amdgcn_readfirstlane(im.dus_per_mcu);
+    const uint32_t tp = __builtin_amdgcn_readfirstlane(tpacked);
+    uint32_t *chk = reinterpret_cast<uint32_t *>(pjd_huff_lds + B.max_lut_bytes);
+    uint32_t *stream = chk + 2 * PJD_NCHK * 64;
     for (int iter = 0; iter < PJD_SYNC_MAX_ITERS; iter++) {
         const uint32_t pp = __shfl_up(S.p_img, 1), pcz = __shfl_up(S.cz, 1), pch = __shfl_up(changed, 1);
         const bool act = g.owned && !g.seg_first && pch != 0;
-        if (!__any(act)) return true;
-        if (stats && threadIdx.x == 0) atomicAdd(stats + stat_base, 1ull);
+        const uint64_t act_mask = __ballot(act);
+        if (!act_mask) return true;
+        const uint64_t tr0 = rdbg ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (stats && t == 0) atomicAdd(stats + stat_base, 1ull);
+        if (stats && act) atomicAdd(stats + stat_base + 1, 1ull);
         changed = 0;
+        uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, err = 0, D = 0;
+        ChkCursor cur = { 1, K.start_bit + K.chk_bits };
+        int res = SPAN_YIELDED;
+        // many lanes: one subsequence per lane, until only a few are still at it
+        if (__popcll(act_mask) > PJD_COOP_START_LANES && act)
+            res = decode_span<MODE_BRIDGE>(tabs, tp, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, cur, PJD_COOP_YIELD_LANES, nullptr, D, 0);
+        if (act && res != SPAN_YIELDED) chk_finish(K, cur.j, ndu);
+        // the rest: the whole wave on one subsequence at a time
+        uint64_t todo = __ballot(act && res == SPAN_YIELDED);
+        while (todo) {
+            const uint32_t L = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            uint32_t sp = __builtin_amdgcn_readlane(p, L), sc = __builtin_amdgcn_readlane(c, L), sz = __builtin_amdgcn_readlane(z, L);
+            uint32_t sn = __builtin_amdgcn_readlane(ndu, L);
+            // (the builtin returns int: without the casts a low half >= 2^31 sign-extends over the high half)
+            const uint64_t bptr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)g.base16 >> 32), L) << 32) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(uint64_t)g.base16, L);
+            const int r = coop_bridge(tabs, tp, nl, dus, reinterpret_cast<const uint4 *>(bptr), B.sub_bytes, sp, sc, sz,
+                                      __builtin_amdgcn_readlane(g.end_bit, L), sn, chk + L, chk + PJD_NCHK * 64 + L,
+                                      __builtin_amdgcn_readlane(K.start_bit, L), __builtin_amdgcn_readfirstlane(K.chk_bits),
+                                      __builtin_amdgcn_readlane(cur.j, L), __builtin_amdgcn_readlane(cur.next_chk, L), stream);
+            if (t == L) { p = sp; c = sc; z = sz; ndu = sn; res = r; }
+        }
+        if (rdbg && t == 0 && iter < 24) rdbg[iter] = ((uint32_t)__popcll(act_mask) << 24) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - tr0) & 0xffffffu);
         if (act) {
-            if (stats) atomicAdd(stats + stat_base + 1, 1ull);
-            uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, err = 0, D = 0;
-            const bool merged = decode_span<MODE_BRIDGE>(tabs, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
             S.cnt = ndu;
-            if (!merged) {
+            if (res != SPAN_MERGED) {
                 const uint32_t np = p + g.base_bit, ncz = (c << 8) | z;
                 if (np != S.p_img || ncz != S.cz) { S.p_img = np; S.cz = ncz; changed = 1; }
             }
@@ -431,6 +573,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
     const PjdDevImage &im = B.images[wg.image];
     uint64_t *exit0 = B.wg_exit, *exit1 = B.wg_exit + B.n_hwg;
     LaneGeom g; uint32_t tpacked; ChkCtx K;
+    const uint64_t ts0 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     wave_setup(B, wg, im, g, tpacked, K);
     const uint32_t nl = im.n_luma, dus = im.dus_per_mcu;
     const bool first_is_head = (B.subs[wg.first_sub].seg >> 31) != 0;
@@ -441,12 +584,18 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
     WaveState S;
     {
         uint32_t p = g.start_bit, c = 0, z = 0, ndu = 0, err = 0, D = 0;
-        if (g.valid) decode_span<MODE_SPEC>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, nullptr, D, 0);
+        ChkCursor cur = { 1, K.start_bit + K.chk_bits };
+        if (g.valid) {
+            decode_span<MODE_SPEC>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, cur, 0, nullptr, D, 0);
+            chk_finish(K, cur.j, ndu);
+        }
         S.p_img = p + g.base_bit; S.cz = (c << 8) | z; S.cnt = ndu;
     }
+    const uint64_t ts1 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     const uint64_t entry0 = pjd_pack_state(__shfl(S.p_img, 0), __shfl(S.cz, 0) >> 8, __shfl(S.cz, 0) & 255);   // lane 0: the assumed entry
-    bool ok = wave_rounds(im, g, tpacked, K, S, g.valid ? 1u : 0u, B.stats, 0);
+    bool ok = wave_rounds(B, im, g, tpacked, K, S, g.valid ? 1u : 0u, B.stats, 0, B.dbg ? B.dbg + (size_t)w * 32 + 8 : nullptr);
     if (t == wg.n_sub) op_store(exit0 + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
+    const uint64_t ts2 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 
     // ---- B: stitch to the predecessor wave: redo this wave's bridges from the true entry if the guess was wrong
     uint64_t entry_used = entry0;
@@ -454,12 +603,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
         const uint64_t truth = op_wait_flag(exit0 + w - 1, dead);
         if (!dead && truth != entry0) {
             if (t == 0) { S.p_img = (uint32_t)truth; S.cz = (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255); S.cnt = 0; }
-            ok = wave_rounds(im, g, tpacked, K, S, t == 0 ? 1u : 0u, B.stats, 2) && ok;
+            ok = wave_rounds(B, im, g, tpacked, K, S, t == 0 ? 1u : 0u, B.stats, 2) && ok;
             entry_used = truth;
         }
     }
     if (t == wg.n_sub) op_store(exit1 + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
     if (!ok) flag = 1;
+    const uint64_t ts3 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 
     // ---- C: counts.  Inside the wave: segmented scan of data units, plain scan of entries ...
     uint32_t cnt = 0, ecnt = 0, v = 0, f = 0, seg_first_du = 0, seg_n_du = 0;
@@ -516,6 +666,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
         if (t == 0) op_store(B.wg_desc + w, op_desc(OP_ST_PFX, iv, ifl, re + agg_e, dead));
     }
 
+    const uint64_t ts4 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     // ---- D: final pass from the true entry states
     const uint32_t prev_p = __shfl_up(S.p_img, 1), prev_cz = __shfl_up(S.cz, 1);
     if (g.owned && !dead) {
@@ -538,7 +689,8 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
         O.acc = make_uint4(0, 0, 0, 0);
         if (g.seg_first) B.seg_ent[g.seg] = O.epos;
         if (D_in < D_end) {
-            decode_span<MODE_WRITE>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, &O, D, D_end);
+            ChkCursor cur = { 1, 0 };
+            decode_span<MODE_WRITE>(pjd_huff_lds, tpacked, nl, dus, g.base16, p, c, z, g.end_bit, ndu, err, K, cur, 0, &O, D, D_end);
             if (err) flag = 1;
             if (D == D_end) {
                 if (p > g.seg_end_bit) flag = 1;
@@ -556,12 +708,19 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
         const uint64_t fin = op_wait_flag(exit1 + w - 1, dead);
         if (fin != entry_used) flag = 1;
     }
+    if (B.dbg && t == 0) {
+        const uint64_t ts5 = __builtin_amdgcn_s_memrealtime();
+        uint32_t *d = B.dbg + (size_t)w * 32;
+        d[0] = (uint32_t)ts0; d[1] = (uint32_t)(ts1 - ts0); d[2] = (uint32_t)(ts2 - ts1); d[3] = (uint32_t)(ts3 - ts2);
+        d[4] = (uint32_t)(ts4 - ts3); d[5] = (uint32_t)(ts5 - ts4); d[6] = wg.image; d[7] = wg.n_sub;
+    }
     if (dead) flag = 1;
     if (flag) atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + 2 * PJD_NCHK * 64 * sizeof(uint32_t); }
+// tables | checkpoints (state, units-to-come: PJD_NCHK x 64 each) | staged subsequence of the cooperative pass
+static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + 2 * PJD_NCHK * 64 * sizeof(uint32_t) + PJD_SUB_BYTES_MAX + 128; }
 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 {

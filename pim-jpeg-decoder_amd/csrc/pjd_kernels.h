@@ -27,6 +27,7 @@ struct PjdDevBatch {
     uint64_t *wg_exit;                   // [2][n_hwg]: exit state of a wave's last owned subsequence | flag; generation 0 / 1
     uint64_t *wg_desc;                   // per Huffman workgroup: look-back descriptor (status | poison | head | units | entries)
     uint32_t *ticket;                    // wave index dispenser
+    uint32_t *dbg;                       // PJD_DEBUG_STATS: per wave, 8 timestamps (10 ns units); else null
     // DC prediction scratch
     uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
     uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
