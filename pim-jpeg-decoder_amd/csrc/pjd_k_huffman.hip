@@ -193,20 +193,30 @@ __device__ __forceinline__ int decode_span(const uint8_t *tabs, uint32_t tpacked
     w.init(base16, p);
     uint32_t j = cur.j, next_chk = cur.next_chk;
     int res = SPAN_END;
-    while (p < end_bit && (MODE != MODE_WRITE || D < D_end)) {
-        if (MODE == MODE_BRIDGE && yield_lanes && (uint32_t)__popcll(__ballot(true)) <= yield_lanes) { res = SPAN_YIELDED; break; }
-        if (MODE != MODE_WRITE && p >= next_chk) {
+    // per data-unit phase c: LUT slot of its DC table (bits 6c..6c+2) and of its AC table (bits 6c+3..6c+5)
+    uint64_t slots = 0;
+    for (uint32_t cc = 0; cc < dus; cc++) {
+        const uint32_t comp = (cc >= nl ? 1u : 0u) + (cc > nl ? 1u : 0u);
+        slots |= (uint64_t)(((tpacked >> (8 * comp)) & 7u) | (((tpacked >> (8 * comp + 4)) & 7u) << 3)) << (6 * cc);
+    }
+    // one compare per symbol covers both "subsequence end" and "next checkpoint"
+    uint32_t lim = (MODE != MODE_WRITE && next_chk < end_bit) ? next_chk : end_bit;
+    for (;;) {
+        if (MODE == MODE_WRITE) { if (p >= end_bit || D >= D_end) break; }
+        else if (p >= lim) {
+            if (p >= end_bit) break;
             const uint32_t st = ((p - K.start_bit) << 12) | (c << 8) | z;      // p-start < 2^14, c < 16, z < 64
             if (MODE == MODE_BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
             K.state[j * 64] = st;
             K.rem[j * 64] = ndu;                                                // turned into "still to come" after the pass
             j++;
             next_chk += K.chk_bits;
+            lim = next_chk < end_bit ? next_chk : end_bit;
         }
+        if (MODE == MODE_BRIDGE && yield_lanes && (uint32_t)__popcll(__ballot(true)) <= yield_lanes) { res = SPAN_YIELDED; break; }
         const uint32_t pk = w.peek();
         const bool is_dc = (z == 0);
-        const uint32_t comp = (c >= nl ? 1u : 0u) + (c > nl ? 1u : 0u);
-        const uint32_t slot = (tpacked >> (8 * comp + (is_dc ? 0u : 4u))) & 15u;
+        const uint32_t slot = (uint32_t)(slots >> (6 * c + (is_dc ? 0u : 3u))) & 7u;
         uint32_t e = *reinterpret_cast<const uint16_t *>(tabs + slot * PJD_L1_BYTES + 2 * (pk >> (32 - PJD_LUT_BITS)));
         // code longer than 10 bits: one more read, in the 64-entry table of this 10-bit prefix
         if (__builtin_expect((e & 0x8000u) != 0, 0))
