@@ -185,8 +185,32 @@ __global__ __launch_bounds__(64) void pjd_k_dc_carry(PjdDevBatch B)
     }
 }
 
+__device__ __forceinline__ void pjd_tile_row(int16_t (*tile)[TILE_STRIDE], uint32_t du, uint32_t r)
+{
+    int4 raw = *reinterpret_cast<const int4 *>(&tile[du][r * 8]);
+    int16_t *rv = reinterpret_cast<int16_t *>(&raw);
+    int o[8];
+    pjd_idct8(rv[0], rv[1], rv[2], rv[3], rv[4], rv[5], rv[6], rv[7], o);
+#pragma unroll
+    for (int j = 0; j < 8; j++) rv[j] = (int16_t)o[j];
+    *reinterpret_cast<int4 *>(&tile[du][r * 8]) = raw;
+}
+
+__device__ __forceinline__ void pjd_tile_col(int16_t (*tile)[TILE_STRIDE], uint32_t du, uint32_t c)
+{
+    int x[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = tile[du][j * 8 + c];
+    pjd_idct8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
+#pragma unroll
+    for (int j = 0; j < 8; j++) tile[du][j * 8 + c] = (int16_t)o[j];
+}
+
 // Row pass, column pass, chroma upsample + colour + raster store for the data units staged in `tile`
 // (natural order, dequantised).  Shared by the sparse and the dense front ends.
+// DO_IDCT = false: the caller has already run both passes on every unit (and this function's first barrier is
+// the one that separates them from the colour stage).
+template <bool DO_IDCT>
 __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE], uint32_t *mcu_xy, const PjdDevBatch &B,
                                                    const PjdDevImage &im, const PjdDevIdctWg &wg, uint32_t tid)
 {
@@ -197,27 +221,12 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
     const uint32_t dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp, hs = im.hs, vs = im.vs;
     const uint32_t n_du = wg.n_mcu * dus;
     __syncthreads();
-    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {      // rows
-        const uint32_t du = i >> 3, r = i & 7;
-        int4 raw = *reinterpret_cast<const int4 *>(&tile[du][r * 8]);
-        int16_t *rv = reinterpret_cast<int16_t *>(&raw);
-        int o[8];
-        pjd_idct8(rv[0], rv[1], rv[2], rv[3], rv[4], rv[5], rv[6], rv[7], o);
-#pragma unroll
-        for (int j = 0; j < 8; j++) rv[j] = (int16_t)o[j];
-        *reinterpret_cast<int4 *>(&tile[du][r * 8]) = raw;
+    if (DO_IDCT) {
+        for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) pjd_tile_row(tile, i >> 3, i & 7);
+        __syncthreads();
+        for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) pjd_tile_col(tile, i >> 3, i & 7);
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {      // columns
-        const uint32_t du = i >> 3, c = i & 7;
-        int x[8], o[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = tile[du][j * 8 + c];
-        pjd_idct8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], o);
-#pragma unroll
-        for (int j = 0; j < 8; j++) tile[du][j * 8 + c] = (int16_t)o[j];
-    }
-    __syncthreads();
 
     // ---- chroma upsample (nearest neighbour, decoder_dpu.c:370), colour, raster store --------
     const uint32_t mw = 8 * hs, mh = 8 * vs;
@@ -360,19 +369,26 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
         }
     }
     __syncthreads();
-    pjd_tile_to_pixels(tile, mcu_xy, B, im, wg, tid);
+    pjd_tile_to_pixels<true>(tile, mcu_xy, B, im, wg, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Sparse front end: the parallel entropy decoder leaves, per data unit, a run of 4-byte entries
 // (value << 16 | zigzag slot, AC only) delimited by du_end[] / seg_ent[], and the DC in dcv[].
 // ---------------------------------------------------------------------------------------------
+// The eight threads that own a data unit (one wave always holds all eight) take it from entries to
+// finished samples on their own: clear, scatter (de-zigzag + dequantise), row pass, column pass.  LDS
+// traffic of one wave is processed in program order, so wave-local fences are all these steps need;
+// the workgroup meets once, before the colour stage, which mixes units of different waves.
+#define PJD_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint16_t qs[3][64];
-    __shared__ uint32_t e_lo[PJD_IDCT_MAX_DU], e_hi[PJD_IDCT_MAX_DU], s52[PJD_IDCT_MAX_DU], mcu_xy[PJD_IDCT_MAX_DU];
-    __shared__ uint8_t zzs[64], du_comp[PJD_IDCT_MAX_DU], du_ml[PJD_IDCT_MAX_DU];
+    __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
+    __shared__ uint8_t zzs[64];
 
     const PjdDevIdctWg wg = wgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
@@ -385,34 +401,27 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
 
     if (tid < 192) qs[tid >> 6][tid & 63] = B.qtab[(size_t)wg.image * 192 + tid];
     if (tid < 64) zzs[tid] = c_zz[tid];
-    {   // clear the tile: unvisited positions are zero (the reference's buffers start zeroed)
-        uint4 *tz = reinterpret_cast<uint4 *>(&tile[0][0]);
-        const uint32_t n16 = n_du * (TILE_STRIDE * 2 / 16);
-        for (uint32_t i = tid; i < n16; i += PJD_IDCT_THREADS) tz[i] = make_uint4(0, 0, 0, 0);
-    }
-    if (tid < n_du) {
-        const uint32_t d = d0 + tid, m = d / dus, k = d - m * dus;
-        const bool seg_first = k == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
-        const uint32_t seg = im.seg_base + (RI ? m / RI - im.first_mcu / RI : 0);
-        const uint32_t *de = B.du_end + im.du_base;
-        e_lo[tid] = seg_first ? B.seg_ent[seg] : de[d - 1];
-        e_hi[tid] = de[d];
-        s52[tid] = 0;
-        du_comp[tid] = (uint8_t)(k < nl ? 0 : k - nl + 1);
-        du_ml[tid] = (uint8_t)(tid / dus);
-    }
     __syncthreads();
 
     const uint32_t *ent = B.ent + im.ent_base;
-    const int16_t *dcv = B.dcv + im.du_base + d0;
+    const uint32_t *de = B.du_end + im.du_base;
+    const int16_t *dcv = B.dcv + im.du_base;
     for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
         const uint32_t du = i >> 3, r = i & 7;
-        const uint32_t comp = du_comp[du];
+        const uint32_t d = d0 + du, m = d / dus, k = d - m * dus;
+        const uint32_t comp = k < nl ? 0 : k - nl + 1;
         const uint16_t *q = qs[comp];
         int16_t *t = tile[du];
+        // this unit's entries: [lo, hi) of the image's stream (the eight threads read the same two words)
+        const bool seg_first = k == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
+        const uint32_t lo = seg_first ? B.seg_ent[im.seg_base + (RI ? m / RI - im.first_mcu / RI : 0)] : de[d - 1];
+        const uint32_t hi = de[d];
+        // unvisited positions are zero (the reference's buffers start zeroed): 144 bytes = 9 x 16
+        *reinterpret_cast<uint4 *>(t + r * 8) = make_uint4(0, 0, 0, 0);
+        if (r == 0) *reinterpret_cast<uint4 *>(t + 64) = make_uint4(0, 0, 0, 0);
+        PJD_WAVE_SYNC();
         if (r == 0) {
-            int dc = dcv[du];
-            const uint32_t m = wg.first_mcu + du_ml[du];
+            int dc = dcv[d];
             const uint32_t blk = m / PJD_DC_BLOCK;
             const uint32_t hm = RI ? (m / RI) * RI : 0;          // last restart point at or before m
             if (hm < blk * PJD_DC_BLOCK) {                        // none inside this scan block: carry applies
@@ -421,20 +430,23 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
             }
             t[0] = (int16_t)pjd_dequant(dc, q[0]);
         }
-        const uint32_t hi = e_hi[du];
-        for (uint32_t e = e_lo[du] + r; e < hi; e += 8) {
+        uint32_t s52 = 0;                                        // entry at slot 52, if this thread met it
+        for (uint32_t e = lo + r; e < hi; e += 8) {
             const uint32_t w = ent[e];
             const uint32_t slot = w & 63;
             const int val = (int)(int16_t)(w >> 16);
-            if (slot == 52) s52[du] = 0x80000000u | (w >> 16);     // overrides slot 48 at natural 38, even when zero
+            if (slot == 52) s52 = 0x80000000u | (w >> 16);       // overrides slot 48 at natural 38, even when zero
             else { const uint32_t nat = zzs[slot]; t[nat] = (int16_t)pjd_dequant(val, q[nat]); }
         }
+        s52 |= __shfl_xor(s52, 1); s52 |= __shfl_xor(s52, 2); s52 |= __shfl_xor(s52, 4);   // a unit visits slot 52 at most once
+        PJD_WAVE_SYNC();
+        if (s52 && r == 0) t[38] = (int16_t)pjd_dequant((int)(int16_t)(s52 & 0xffffu), q[38]);
+        PJD_WAVE_SYNC();
+        pjd_tile_row(tile, du, r);
+        PJD_WAVE_SYNC();
+        pjd_tile_col(tile, du, r);
     }
-    __syncthreads();
-    if (tid < n_du && s52[tid])
-        tile[tid][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[tid] & 0xffffu), qs[du_comp[tid]][38]);
-    __syncthreads();
-    pjd_tile_to_pixels(tile, mcu_xy, B, im, wg, tid);
+    pjd_tile_to_pixels<false>(tile, mcu_xy, B, im, wg, tid);
 }
 
 void pjd_launch_idct_colour_sparse(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)
