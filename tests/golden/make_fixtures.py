@@ -180,7 +180,46 @@ def build_set():
     e0 = sos_end(d)
     k = d.find(b"\xff\xd0", e0)
     S["fill_ff_before_rst_444"] = d[:k] + b"\xff\xff" + d[k:]
+    # --- odd Huffman tables (the scan then decodes to whatever the reference makes of it) ---------
+    base = enc(picture(96, 64, 61), quality=90, subsampling=0)
+    ac_syms = [s for s in range(256) if (s & 15) <= 10 and (s & 15 or s in (0x00, 0xF0))]      # the 162 baseline AC symbols
+    # 3 short codes + 159 codes of 11 bits in BOTH AC tables: 80 ten-bit prefixes with long codes per table,
+    # more second-level tables than the parallel decoder keeps in LDS -> exact kernel
+    counts = [1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 159, 0, 0, 0, 0, 0]
+    S["huff_longtail_96x64_444"] = replace_dht(base, {(1, 0): (counts, ac_syms), (1, 1): (counts, ac_syms[:3] + ac_syms[:2:-1])})
+    # over-subscribed table: three codes of one bit (reference generate_codes just keeps counting)
+    counts = [3, 1, 2, 4] + [0] * 12
+    S["huff_oversub_96x64_444"] = replace_dht(base, {(1, 0): (counts, ac_syms[:10])})
     return S
+
+
+def replace_dht(data, new):
+    """Rewrite the DHT segments: `new` maps (table class, table id) -> (16 counts, symbols); others are kept."""
+    out, i = bytearray(data[:2]), 2
+    while i < len(data):
+        assert data[i] == 0xFF
+        m = data[i + 1]
+        if m == 0xDA:
+            out += data[i:]
+            break
+        n = (data[i + 2] << 8) | data[i + 3]
+        seg = data[i + 4:i + 2 + n]
+        if m == 0xC4:
+            j, body = 0, bytearray()
+            while j < len(seg):
+                tc, th = seg[j] >> 4, seg[j] & 15
+                cnt = list(seg[j + 1:j + 17])
+                syms = list(seg[j + 17:j + 17 + sum(cnt)])
+                j += 17 + sum(cnt)
+                if (tc, th) in new:
+                    cnt, syms = new[(tc, th)]
+                    assert len(cnt) == 16 and sum(cnt) == len(syms)
+                body += bytes([(tc << 4) | th]) + bytes(cnt) + bytes(syms)
+            out += bytes([0xFF, 0xC4, (len(body) + 2) >> 8, (len(body) + 2) & 255]) + body
+        else:
+            out += data[i:i + 2 + n]
+        i += 2 + n
+    return bytes(out)
 
 
 def main():

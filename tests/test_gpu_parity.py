@@ -182,8 +182,10 @@ def test_routing_parallel_path_is_the_one_that_runs(ctx):
             b.decode()
             b.download()
             i = b.info()
-        if name.startswith("div_rst"):
-            assert i["n_sequential"] == 1, name          # reference restart rule with subsampled luma
+        if name.startswith("div_rst") or name.startswith("huff_"):
+            # reference restart rule with subsampled luma / Huffman tables the parallel decoder does not take
+            # (more long-code prefixes than its LDS budget; an over-subscribed code): exact kernel up front
+            assert i["n_sequential"] == 1, name
             continue
         assert i["n_sequential"] == 0, name
         if name in expect_fallback:

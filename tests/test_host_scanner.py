@@ -116,6 +116,16 @@ def test_libpjdpipe_exports_every_declared_symbol():
     pjd_amd.pipe_lib()             # loads together with libpjd / libpjdhost (no compute call)
 
 
+def test_plan_routes_odd_huffman_tables_to_exact_kernel():
+    """Planner only (no GPU): tables with more long-code prefixes than the LDS budget, or not a prefix code at all."""
+    for name in ("huff_longtail_96x64_444", "huff_oversub_96x64_444"):
+        s = pjd_amd.Scanned(golden_bytes(name))
+        assert s.valid
+        assert pjd_amd.plan_info([s.desc])["n_sequential"] == 1, name
+    s = pjd_amd.Scanned(golden_bytes("big_500x375_444_q92_opt"))      # optimised tables with a normal tail: parallel path
+    assert pjd_amd.plan_info([s.desc])["n_sequential"] == 0
+
+
 def test_plan_info_host_only():
     """The planner runs without a device: lanes, data units, routing."""
     descs, keep = [], []
