@@ -367,3 +367,44 @@ def test_download_packed_equals_download(ctx):
     assert sa == sp
     for x, y in zip(a, p):
         assert np.array_equal(x, y)
+
+
+def test_random_streams_one_batch_match_oracle(ctx, port):
+    """240 seeded random pictures (1..260 px per side, all samplings, q 5..100, assorted restart intervals) in ONE
+    batch: every picture equals the oracle's; regular streams stay on the parallel path."""
+    import pjd_amd
+    synth = _synth()
+    rng = np.random.default_rng(20260)
+    jpegs, flags, plain = [], [], []
+    for k in range(240):
+        w, h = int(rng.integers(1, 261)), int(rng.integers(1, 261))
+        sub = int(rng.choice([synth.SUB_444, synth.SUB_422, synth.SUB_420, synth.SUB_440, synth.SUB_GREY]))
+        q = int(rng.choice([5, 25, 50, 75, 90, 100]))
+        hs = 2 if sub in (synth.SUB_422, synth.SUB_420) else 1
+        mcux = (w + 8 * hs - 1) // (8 * hs)
+        ri = int(rng.choice([0, 0, 1, 2, 5, mcux]))
+        pic = synth.picture(w, h, 777 + k)
+        jpegs.append(synth.encode(pic, q, sub, ri))
+        # subsampled luma + DRI: half of them under the reference's own rule (exact kernel, garbled like the
+        # reference garbles them), half under the standard rule (parallel path; equals the picture without DRI)
+        std = ri != 0 and sub in (synth.SUB_422, synth.SUB_420, synth.SUB_440) and k % 2 == 0
+        flags.append(pjd_amd.F_STANDARD_RESTART if std else 0)
+        plain.append(synth.encode(pic, q, sub, 0) if std else None)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    assert all(s.valid for s in scanned)
+    for s, f in zip(scanned, flags):
+        s.desc.flags = f
+    with ctx.batch([s.desc for s in scanned]) as b:
+        b.upload(); b.decode()
+        outs, st = b.download()
+        info = b.info()
+    n_seq = 0
+    for k in range(240):
+        want = port.decode(plain[k] if plain[k] is not None else jpegs[k])
+        assert st[k] == want["huff_rc"], k
+        assert np.array_equal(outs[k], want["rgb"]), k
+        d = scanned[k].desc
+        if d.restart_interval and (d.h_samp, d.v_samp) != (1, 1) and not flags[k]:
+            n_seq += 1
+    assert info["n_sequential"] == n_seq
+    assert info["n_fallback"] == 0
