@@ -7,7 +7,10 @@ One process per GPU (the driver launches N ranks with torch.distributed.run); ev
 OWN batch (weak scaling, no data-path collective: images are independent).  A step = one pass of the
 whole hot path (Huffman entropy decode -> dequantise -> IDCT -> upsample -> YCbCr->RGB) over one
 batch whose bitstreams, tables and work lists are already resident in HBM; pictures stay in HBM.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Beside the contract fields it carries `roofline` (dominant kernel: algorithmic
+bytes / HIP-event duration against the HBM peak, PMC traffic from profiles/), `cpu_baseline` (oracle/_ref = the
+reference's own host code on one core, same JPEGs) and, at N=1, `pcie_inclusive`: the same files through the
+pipelined batcher (libpjdpipe) from JPEG bytes in host memory to BMP bytes in page-locked host memory -- never `value`.
 
 Workloads (synthetic and seeded -- there is no dataset on the box; tools/synth.py):
     cfg3     M (default 1024) ImageNet-like 4:2:0 JPEGs of mixed sizes per GPU, hipGraph replay  [default]
