@@ -8,7 +8,7 @@
 
 // ---- tunables -----------------------------------------------------------------
 #define PJD_SUB_BYTES_MIN  128      // Huffman subsequence (bytes of bitstream per decode lane): chosen per batch
-#define PJD_SUB_BYTES_MAX  1024     //   by the planner (power of two in this range), see pjd_plan.cpp
+#define PJD_SUB_BYTES_MAX  1024     //   by the planner (multiple of 64 in this range), see pjd_plan.cpp
 #define PJD_HUFF_THREADS   64       // one wave per Huffman workgroup: lanes exchange states by shuffles, no barriers
 #define PJD_HUFF_OWNED     63       // subsequences owned per workgroup (lane 0 = predecessor overlap)
 #define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into)

@@ -54,8 +54,8 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         for (int i = 0; i < n; i++) total += images[i].ecs_len;
         uint32_t sb = total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u);
         if (sub_bytes_override) {
-            if (sub_bytes_override < PJD_SUB_BYTES_MIN || sub_bytes_override > PJD_SUB_BYTES_MAX || (sub_bytes_override & (sub_bytes_override - 1))) {
-                err = "sub_bytes override must be a power of two in [128, 1024]";
+            if (sub_bytes_override < PJD_SUB_BYTES_MIN || sub_bytes_override > PJD_SUB_BYTES_MAX || (sub_bytes_override & 63)) {
+                err = "sub_bytes override must be a multiple of 64 in [128, 1024]";
                 return PJD_E_ARG;
             }
             sb = sub_bytes_override;

@@ -39,6 +39,6 @@ struct PjdPlan {
 };
 
 // Returns PJD_OK or PJD_E_ARG (with a message in `err`).
-// sub_bytes_override: 0 = choose from the batch size, else a power of two in [PJD_SUB_BYTES_MIN, PJD_SUB_BYTES_MAX].
+// sub_bytes_override: 0 = choose from the batch size, else a multiple of 64 in [PJD_SUB_BYTES_MIN, PJD_SUB_BYTES_MAX].
 int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &plan, std::string &err,
                   uint32_t sub_bytes_override = 0);
