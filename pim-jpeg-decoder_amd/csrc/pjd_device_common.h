@@ -20,16 +20,21 @@ static __constant__ uint8_t c_zz[64] = {
 // One 1-D pass of the reference's integer butterfly (reference
 // src/decoder_dpu.c:219-267 rows, :271-319 columns).  32-bit ints, arithmetic
 // shifts, no rounding terms; the caller truncates the outputs to int16.
+//
+// All operands are within 24 bits when the inputs are int16 (they always are: dequantised coefficients and
+// first-pass outputs are stored as int16): |g| <= 32768*251/8, sums of two or three of those stay below 2^23.
+// __mul24 then returns exactly the low 32 bits of the reference's 32-bit product -- at full rate instead of the
+// quarter-rate v_mul_lo_u32.
 __device__ __forceinline__ void pjd_idct8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7, int *o)
 {
-    const int g0 = (x0 * 181) >> 5, g1 = (x4 * 181) >> 5;
-    const int g2 = (x2 * 59) >> 3,  g3 = (x6 * 49) >> 4;
-    const int g4 = (x5 * 71) >> 4,  g5 = (x1 * 251) >> 5;
-    const int g6 = (x7 * 25) >> 4,  g7 = (x3 * 213) >> 5;
+    const int g0 = __mul24(x0, 181) >> 5, g1 = __mul24(x4, 181) >> 5;
+    const int g2 = __mul24(x2, 59) >> 3,  g3 = __mul24(x6, 49) >> 4;
+    const int g4 = __mul24(x5, 71) >> 4,  g5 = __mul24(x1, 251) >> 5;
+    const int g6 = __mul24(x7, 25) >> 4,  g7 = __mul24(x3, 213) >> 5;
     const int f4 = g4 - g7, f5 = g5 + g6, f6 = g5 - g6, f7 = g4 + g7;
     const int e2 = g2 - g3, e3 = g2 + g3, e5 = f5 - f7, e7 = f5 + f7, e8 = f4 + f6;
-    const int d2 = (e2 * 181) >> 7, d4 = (f4 * 277) >> 8, d5 = (e5 * 181) >> 7;
-    const int d6 = (f6 * 669) >> 8, d8 = (e8 * 49) >> 6;
+    const int d2 = __mul24(e2, 181) >> 7, d4 = __mul24(f4, 277) >> 8, d5 = __mul24(e5, 181) >> 7;
+    const int d6 = __mul24(f6, 669) >> 8, d8 = __mul24(e8, 49) >> 6;
     const int c0 = g0 + g1, c1 = g0 - g1, c2 = d2 - e3, c4 = d4 + d8;
     const int c5 = d5 + e7, c6 = d6 - d8, c8 = c5 - c6;
     const int b0 = c0 + e3, b1 = c1 + c2, b2 = c1 - c2, b3 = c0 - e3, b4 = c4 - c8, b6 = c6 - e7;
@@ -43,11 +48,13 @@ __device__ __forceinline__ int pjd_clamp255(int v) { return v < 0 ? 0 : (v > 255
 // 0.714, 1.772 scaled by 2^22, every product shifted on its own, +128, clamp.
 __device__ __forceinline__ void pjd_ycc_to_rgb(int y, int cb, int cr, int &r, int &g, int &b)
 {
-    r = pjd_clamp255(y + ((int)(5880414u * (unsigned)cr) >> 22) + 128);
-    g = pjd_clamp255(y - ((int)(1442840u * (unsigned)cb) >> 22) - ((int)(2994733u * (unsigned)cr) >> 22) + 128);
-    b = pjd_clamp255(y + ((int)(7432306u * (unsigned)cb) >> 22) + 128);
+    // cb, cr are int16 samples and the constants are below 2^23: __mul24 == the low 32 bits of the 32-bit product
+    r = pjd_clamp255(y + (__mul24(5880414, cr) >> 22) + 128);
+    g = pjd_clamp255(y - (__mul24(1442840, cb) >> 22) - (__mul24(2994733, cr) >> 22) + 128);
+    b = pjd_clamp255(y + (__mul24(7432306, cb) >> 22) + 128);
 }
 
 // Dequantise: short *= u32 with the product truncated to int16 on store
 // (reference src/decoder_dpu.c:169-172); only the low 16 bits of q matter.
-__device__ __forceinline__ int pjd_dequant(int coef, unsigned q) { return (int)(int16_t)((unsigned)coef * q); }
+// coef is an int16 value, q < 2^16: within __mul24's exact range
+__device__ __forceinline__ int pjd_dequant(int coef, unsigned q) { return (int)(int16_t)__mul24(coef, (int)q); }

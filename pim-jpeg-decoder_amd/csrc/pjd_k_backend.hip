@@ -406,46 +406,73 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
     const uint32_t *ent = B.ent + im.ent_base;
     const uint32_t *de = B.du_end + im.du_base;
     const int16_t *dcv = B.dcv + im.du_base;
-    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
-        const uint32_t du = i >> 3, r = i & 7;
-        const uint32_t d = d0 + du, m = d / dus, k = d - m * dus;
-        const uint32_t comp = k < nl ? 0 : k - nl + 1;
-        const uint16_t *q = qs[comp];
-        int16_t *t = tile[du];
-        // this unit's entries: [lo, hi) of the image's stream (the eight threads read the same two words)
-        const bool seg_first = k == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
-        const uint32_t lo = seg_first ? B.seg_ent[im.seg_base + (RI ? m / RI - im.first_mcu / RI : 0)] : de[d - 1];
-        const uint32_t hi = de[d];
-        // unvisited positions are zero (the reference's buffers start zeroed): 144 bytes = 9 x 16
-        *reinterpret_cast<uint4 *>(t + r * 8) = make_uint4(0, 0, 0, 0);
-        if (r == 0) *reinterpret_cast<uint4 *>(t + 64) = make_uint4(0, 0, 0, 0);
-        PJD_WAVE_SYNC();
-        if (r == 0) {
-            int dc = dcv[d];
-            const uint32_t blk = m / PJD_DC_BLOCK;
-            const uint32_t hm = RI ? (m / RI) * RI : 0;          // last restart point at or before m
-            if (hm < blk * PJD_DC_BLOCK) {                        // none inside this scan block: carry applies
-                const uint32_t *c = B.dc_carry + (size_t)(im.dcblk_base + blk) * 4;
-                dc = (int)(int16_t)((uint32_t)dc + c[comp]);
+    // A thread owns one eighth of up to NIT data units.  Everything it needs from HBM is requested before
+    // anything is used: bounds and DC of all its units, then the first entry of each (a unit rarely has more
+    // than eight entries), so a workgroup waits for two memory round trips, not six.
+    constexpr int NIT = PJD_IDCT_MAX_DU * 8 / PJD_IDCT_THREADS;
+    uint32_t lo[NIT], hi[NIT], comp[NIT], w0[NIT], s52[NIT];
+    int dc[NIT];
+    bool on[NIT];
+    const uint32_t r = tid & 7;
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const uint32_t du = (tid >> 3) + k * (PJD_IDCT_THREADS / 8);
+        on[k] = du < n_du;
+        lo[k] = hi[k] = 0; comp[k] = 0; dc[k] = 0;
+        if (on[k]) {
+            const uint32_t d = d0 + du, m = d / dus, kk = d - m * dus;
+            comp[k] = kk < nl ? 0 : kk - nl + 1;
+            // this unit's entries: [lo, hi) of the image's stream (the eight threads read the same two words)
+            const bool seg_first = kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
+            lo[k] = seg_first ? B.seg_ent[im.seg_base + (RI ? m / RI - im.first_mcu / RI : 0)] : de[d - 1];
+            hi[k] = de[d];
+            if (r == 0) {
+                dc[k] = dcv[d];
+                const uint32_t blk = m / PJD_DC_BLOCK;
+                const uint32_t hm = RI ? (m / RI) * RI : 0;      // last restart point at or before m
+                if (hm < blk * PJD_DC_BLOCK)                      // none inside this scan block: carry applies
+                    dc[k] = (int)(int16_t)((uint32_t)dc[k] + B.dc_carry[(size_t)(im.dcblk_base + blk) * 4 + comp[k]]);
             }
-            t[0] = (int16_t)pjd_dequant(dc, q[0]);
+            // unvisited positions are zero (the reference's buffers start zeroed): 144 bytes = 9 x 16
+            int16_t *t = tile[du];
+            *reinterpret_cast<uint4 *>(t + r * 8) = make_uint4(0, 0, 0, 0);
+            if (r == 0) *reinterpret_cast<uint4 *>(t + 64) = make_uint4(0, 0, 0, 0);
         }
-        uint32_t s52 = 0;                                        // entry at slot 52, if this thread met it
-        for (uint32_t e = lo + r; e < hi; e += 8) {
-            const uint32_t w = ent[e];
-            const uint32_t slot = w & 63;
-            const int val = (int)(int16_t)(w >> 16);
-            if (slot == 52) s52 = 0x80000000u | (w >> 16);       // overrides slot 48 at natural 38, even when zero
-            else { const uint32_t nat = zzs[slot]; t[nat] = (int16_t)pjd_dequant(val, q[nat]); }
-        }
-        s52 |= __shfl_xor(s52, 1); s52 |= __shfl_xor(s52, 2); s52 |= __shfl_xor(s52, 4);   // a unit visits slot 52 at most once
-        PJD_WAVE_SYNC();
-        if (s52 && r == 0) t[38] = (int16_t)pjd_dequant((int)(int16_t)(s52 & 0xffffu), q[38]);
-        PJD_WAVE_SYNC();
-        pjd_tile_row(tile, du, r);
-        PJD_WAVE_SYNC();
-        pjd_tile_col(tile, du, r);
     }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) w0[k] = (on[k] && lo[k] + r < hi[k]) ? ent[lo[k] + r] : 0xffffffffu;
+    PJD_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        s52[k] = 0;                                              // entry at slot 52, if this thread met it
+        if (on[k]) {
+            const uint32_t du = (tid >> 3) + k * (PJD_IDCT_THREADS / 8);
+            const uint16_t *q = qs[comp[k]];
+            int16_t *t = tile[du];
+            if (r == 0) t[0] = (int16_t)pjd_dequant(dc[k], q[0]);
+            uint32_t w = w0[k];
+            for (uint32_t e = lo[k] + r; e < hi[k]; ) {
+                const uint32_t slot = w & 63;
+                const int val = (int)(int16_t)(w >> 16);
+                if (slot == 52) s52[k] = 0x80000000u | (w >> 16);   // overrides slot 48 at natural 38, even when zero
+                else { const uint32_t nat = zzs[slot]; t[nat] = (int16_t)pjd_dequant(val, q[nat]); }
+                e += 8;
+                if (e < hi[k]) w = ent[e];
+            }
+        }
+        s52[k] |= __shfl_xor(s52[k], 1); s52[k] |= __shfl_xor(s52[k], 2); s52[k] |= __shfl_xor(s52[k], 4);   // a unit visits slot 52 at most once
+    }
+    PJD_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < NIT; k++)
+        if (on[k] && s52[k] && r == 0)
+            tile[(tid >> 3) + k * (PJD_IDCT_THREADS / 8)][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[k] & 0xffffu), qs[comp[k]][38]);
+    PJD_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < NIT; k++) if (on[k]) pjd_tile_row(tile, (tid >> 3) + k * (PJD_IDCT_THREADS / 8), r);
+    PJD_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < NIT; k++) if (on[k]) pjd_tile_col(tile, (tid >> 3) + k * (PJD_IDCT_THREADS / 8), r);
     pjd_tile_to_pixels<false>(tile, mcu_xy, B, im, wg, tid);
 }
 
