@@ -42,7 +42,12 @@ __device__ __forceinline__ void pjd_idct8(int x0, int x1, int x2, int x3, int x4
     o[4] = (b3 - b4) >> 4; o[5] = (b2 - c8) >> 4; o[6] = (b1 - b6) >> 4; o[7] = (b0 - e7) >> 4;
 }
 
-__device__ __forceinline__ int pjd_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int pjd_clamp255(int v)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(255));      // one instruction instead of max + min
+    return r;
+}
 
 // Fixed-point YCbCr -> RGB (reference src/decoder_dpu.c:376-382): 1.402, 0.344,
 // 0.714, 1.772 scaled by 2^22, every product shifted on its own, +128, clamp.

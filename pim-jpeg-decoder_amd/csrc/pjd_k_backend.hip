@@ -232,6 +232,8 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
     const uint32_t mw = 8 * hs, mh = 8 * vs;
     const bool bmp = (im.flags & PJD_IF_BMP) != 0;
     uint8_t *out = B.out + im.out_off;
+    // image constants in registers: read through `im` they are re-fetched from HBM after every store
+    const uint32_t width = im.width, height = im.height, stride = im.out_stride;
     if (bmp && wg.first_mcu == 0 && tid < 26) {
         // file header exactly as reference src/bmp_writer.cpp:32-41
         const uint32_t size = 26 + im.height * im.out_stride;
@@ -261,7 +263,7 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
             const uint32_t ml = it >> q_log, px0 = (it & ((1u << q_log) - 1)) * 4;
             const uint32_t xy = mcu_xy[ml];
             const uint32_t X = (xy & 0xffffu) * mw + px0, Y = (xy >> 16) * mh + py;
-            if (X >= im.width || Y >= im.height) continue;
+            if (X >= width || Y >= height) continue;
             const uint32_t d0 = ml * dus;
             const int16_t *yp = &tile[d0 + lrow + (px0 >> 3)][yoff + (px0 & 7)];
             const uint2 yraw = *reinterpret_cast<const uint2 *>(yp);               // 4 luma samples
@@ -295,9 +297,9 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
                 pjd_ycc_to_rgb(y2, cb[2], cr[2], rr, gg, bb); f2 = bmp ? bb : rr; g2 = gg; l2 = bmp ? rr : bb;
                 pjd_ycc_to_rgb(y3, cb[3], cr[3], rr, gg, bb); f3 = bmp ? bb : rr; g3 = gg; l3 = bmp ? rr : bb;
             }
-            uint8_t *o = bmp ? out + 26 + (size_t)(im.height - 1 - Y) * im.out_stride + X * 3
-                             : out + (size_t)Y * im.out_stride + X * 3;
-            if (X + 4 <= im.width) {
+            uint8_t *o = bmp ? out + 26 + (size_t)(height - 1 - Y) * stride + X * 3
+                             : out + (size_t)Y * stride + X * 3;
+            if (X + 4 <= width) {
                 Px12 v;
                 v.a = f0 | (g0 << 8) | (l0 << 16) | (f1 << 24);
                 v.b = g1 | (l1 << 8) | (f2 << 16) | (g2 << 24);
@@ -305,8 +307,8 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
                 *reinterpret_cast<Px12 *>(o) = v;
             } else {                                                             // right picture edge
                 o[0] = (uint8_t)f0; o[1] = (uint8_t)g0; o[2] = (uint8_t)l0;
-                if (X + 1 < im.width) { o[3] = (uint8_t)f1; o[4] = (uint8_t)g1; o[5] = (uint8_t)l1; }
-                if (X + 2 < im.width) { o[6] = (uint8_t)f2; o[7] = (uint8_t)g2; o[8] = (uint8_t)l2; }
+                if (X + 1 < width) { o[3] = (uint8_t)f1; o[4] = (uint8_t)g1; o[5] = (uint8_t)l1; }
+                if (X + 2 < width) { o[6] = (uint8_t)f2; o[7] = (uint8_t)g2; o[8] = (uint8_t)l2; }
             }
         }
     }
