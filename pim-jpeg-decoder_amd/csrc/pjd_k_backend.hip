@@ -262,41 +262,41 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
         for (uint32_t it = tid & 63; it < items; it += 64) {
             const uint32_t ml = it >> q_log, px0 = (it & ((1u << q_log) - 1)) * 4;
             const uint32_t xy = mcu_xy[ml];
-            const uint32_t X = (xy & 0xffffu) * mw + px0, Y = (xy >> 16) * mh + py;
+            const uint32_t X = __umul24(xy & 0xffffu, mw) + px0, Y = __umul24(xy >> 16, mh) + py;
             if (X >= width || Y >= height) continue;
-            const uint32_t d0 = ml * dus;
+            const uint32_t d0 = __umul24(ml, dus);
             const int16_t *yp = &tile[d0 + lrow + (px0 >> 3)][yoff + (px0 & 7)];
             const uint2 yraw = *reinterpret_cast<const uint2 *>(yp);               // 4 luma samples
             const int y0 = (int16_t)(yraw.x & 0xffff), y1 = (int16_t)(yraw.x >> 16), y2 = (int16_t)(yraw.y & 0xffff), y3 = (int16_t)(yraw.y >> 16);
-            int cb[4] = {0, 0, 0, 0}, cr[4] = {0, 0, 0, 0};      // constant indices only: stay in registers
+            // chroma terms of pjd_ycc_to_rgb, once per chroma SAMPLE (two pixels share one when hs == 2), already
+            // ordered first / middle / last output byte (R,G,B -- or B,G,R for the BMP image) and with the +128
             const uint32_t q = cy * 8 + (px0 >> hs_log);
-            if (nc > 1) {
-                if (hs == 2) {                                                       // 2 chroma samples cover 4 pixels
-                    const uint32_t w = *reinterpret_cast<const uint32_t *>(&tile[d0 + nl][q]);
-                    cb[0] = cb[1] = (int16_t)(w & 0xffff); cb[2] = cb[3] = (int16_t)(w >> 16);
-                } else {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(&tile[d0 + nl][q]);
-                    cb[0] = (int16_t)(w.x & 0xffff); cb[1] = (int16_t)(w.x >> 16); cb[2] = (int16_t)(w.y & 0xffff); cb[3] = (int16_t)(w.y >> 16);
+            int cf[4], cg[4], cl[4];
+            const int n_chroma = hs == 2 ? 2 : 4;
+            uint2 cbw = make_uint2(0, 0), crw = make_uint2(0, 0);
+            if (nc > 1) { if (hs == 2) cbw.x = *reinterpret_cast<const uint32_t *>(&tile[d0 + nl][q]); else cbw = *reinterpret_cast<const uint2 *>(&tile[d0 + nl][q]); }
+            if (nc > 2) { if (hs == 2) crw.x = *reinterpret_cast<const uint32_t *>(&tile[d0 + nl + 1][q]); else crw = *reinterpret_cast<const uint2 *>(&tile[d0 + nl + 1][q]); }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j < n_chroma) {
+                    const uint32_t bw = j < 2 ? cbw.x : cbw.y, rw = j < 2 ? crw.x : crw.y;
+                    const int cbv = (j & 1) ? (int)(int16_t)(bw >> 16) : (int)(int16_t)(bw & 0xffff);
+                    const int crv = (j & 1) ? (int)(int16_t)(rw >> 16) : (int)(int16_t)(rw & 0xffff);
+                    const int rC = (__mul24(5880414, crv) >> 22) + 128, bC = (__mul24(7432306, cbv) >> 22) + 128;
+                    cg[j] = 128 - (__mul24(1442840, cbv) >> 22) - (__mul24(2994733, crv) >> 22);
+                    cf[j] = bmp ? bC : rC;
+                    cl[j] = bmp ? rC : bC;
                 }
             }
-            if (nc > 2) {
-                if (hs == 2) {
-                    const uint32_t w = *reinterpret_cast<const uint32_t *>(&tile[d0 + nl + 1][q]);
-                    cr[0] = cr[1] = (int16_t)(w & 0xffff); cr[2] = cr[3] = (int16_t)(w >> 16);
-                } else {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(&tile[d0 + nl + 1][q]);
-                    cr[0] = (int16_t)(w.x & 0xffff); cr[1] = (int16_t)(w.x >> 16); cr[2] = (int16_t)(w.y & 0xffff); cr[3] = (int16_t)(w.y >> 16);
-                }
-            }
-            // first / middle / last byte of each pixel: R,G,B -- or B,G,R for the BMP image
-            uint32_t f0, f1, f2, f3, g0, g1, g2, g3, l0, l1, l2, l3;
-            {
-                int rr, gg, bb;
-                pjd_ycc_to_rgb(y0, cb[0], cr[0], rr, gg, bb); f0 = bmp ? bb : rr; g0 = gg; l0 = bmp ? rr : bb;
-                pjd_ycc_to_rgb(y1, cb[1], cr[1], rr, gg, bb); f1 = bmp ? bb : rr; g1 = gg; l1 = bmp ? rr : bb;
-                pjd_ycc_to_rgb(y2, cb[2], cr[2], rr, gg, bb); f2 = bmp ? bb : rr; g2 = gg; l2 = bmp ? rr : bb;
-                pjd_ycc_to_rgb(y3, cb[3], cr[3], rr, gg, bb); f3 = bmp ? bb : rr; g3 = gg; l3 = bmp ? rr : bb;
-            }
+            const int s1 = hs == 2 ? 0 : 1, s2 = hs == 2 ? 1 : 2, s3 = hs == 2 ? 1 : 3;   // chroma sample of pixels 1..3
+            const int cf1 = s1 ? cf[1] : cf[0], cg1 = s1 ? cg[1] : cg[0], cl1 = s1 ? cl[1] : cl[0];
+            const int cf2 = s2 == 2 ? cf[2] : cf[1], cg2 = s2 == 2 ? cg[2] : cg[1], cl2 = s2 == 2 ? cl[2] : cl[1];
+            const int cf3 = s3 == 3 ? cf[3] : cf[1], cg3 = s3 == 3 ? cg[3] : cg[1], cl3 = s3 == 3 ? cl[3] : cl[1];
+            // reference src/decoder_dpu.c:376-382: y + term + 128, clamped
+            const uint32_t f0 = pjd_clamp255(y0 + cf[0]), g0 = pjd_clamp255(y0 + cg[0]), l0 = pjd_clamp255(y0 + cl[0]);
+            const uint32_t f1 = pjd_clamp255(y1 + cf1), g1 = pjd_clamp255(y1 + cg1), l1 = pjd_clamp255(y1 + cl1);
+            const uint32_t f2 = pjd_clamp255(y2 + cf2), g2 = pjd_clamp255(y2 + cg2), l2 = pjd_clamp255(y2 + cl2);
+            const uint32_t f3 = pjd_clamp255(y3 + cf3), g3 = pjd_clamp255(y3 + cg3), l3 = pjd_clamp255(y3 + cl3);
             uint8_t *o = bmp ? out + 26 + (size_t)(height - 1 - Y) * stride + X * 3
                              : out + (size_t)Y * stride + X * 3;
             if (X + 4 <= width) {
