@@ -388,9 +388,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
-    __shared__ uint16_t qs[3][64];
+    __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
     __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
-    __shared__ uint8_t zzs[64];
 
     const PjdDevIdctWg wg = wgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
@@ -401,8 +400,10 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
     const uint32_t RI = im.restart_interval;
     const uint32_t d0 = wg.first_mcu * dus;                     // image-relative index of the first unit
 
-    if (tid < 192) qs[tid >> 6][tid & 63] = B.qtab[(size_t)wg.image * 192 + tid];
-    if (tid < 64) zzs[tid] = c_zz[tid];
+    if (tid < 192) {
+        const uint32_t nat = c_zz[tid & 63];
+        qz[tid >> 6][tid & 63] = (uint32_t)B.qtab[(size_t)wg.image * 192 + (tid & ~63u) + nat] | (nat << 16);
+    }
     __syncthreads();
 
     const uint32_t *ent = B.ent + im.ent_base;
@@ -449,15 +450,15 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
         s52[k] = 0;                                              // entry at slot 52, if this thread met it
         if (on[k]) {
             const uint32_t du = (tid >> 3) + k * (PJD_IDCT_THREADS / 8);
-            const uint16_t *q = qs[comp[k]];
+            const uint32_t *q = qz[comp[k]];
             int16_t *t = tile[du];
-            if (r == 0) t[0] = (int16_t)pjd_dequant(dc[k], q[0]);
+            if (r == 0) t[0] = (int16_t)pjd_dequant(dc[k], q[0] & 0xffffu);
             uint32_t w = w0[k];
             for (uint32_t e = lo[k] + r; e < hi[k]; ) {
                 const uint32_t slot = w & 63;
                 const int val = (int)(int16_t)(w >> 16);
                 if (slot == 52) s52[k] = 0x80000000u | (w >> 16);   // overrides slot 48 at natural 38, even when zero
-                else { const uint32_t nat = zzs[slot]; t[nat] = (int16_t)pjd_dequant(val, q[nat]); }
+                else { const uint32_t e = q[slot]; t[e >> 16] = (int16_t)pjd_dequant(val, e & 0xffffu); }
                 e += 8;
                 if (e < hi[k]) w = ent[e];
             }
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(Pjd
 #pragma unroll
     for (int k = 0; k < NIT; k++)
         if (on[k] && s52[k] && r == 0)
-            tile[(tid >> 3) + k * (PJD_IDCT_THREADS / 8)][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[k] & 0xffffu), qs[comp[k]][38]);
+            tile[(tid >> 3) + k * (PJD_IDCT_THREADS / 8)][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[k] & 0xffffu), qz[comp[k]][48] & 0xffffu);   // slot 48 -> natural 38
     PJD_WAVE_SYNC();
 #pragma unroll
     for (int k = 0; k < NIT; k++) if (on[k]) pjd_tile_row(tile, (tid >> 3) + k * (PJD_IDCT_THREADS / 8), r);
