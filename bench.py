@@ -196,7 +196,7 @@ def main():
         # gfx950 correction + WRITE_SIZE, both KiB); only valid for the workload it was collected on
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_onepass_cfg3_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_onepass_cfg3_traffic.json")))
             if args.workload == "cfg3" and args.images == 1024:
                 for k, v in tj["per_kernel"].items():
                     if dom in k:
