@@ -121,7 +121,7 @@ typedef struct pjd_batch_info {
     uint64_t pixels;                   /* sum of width*height                                 */
     uint64_t ecs_bytes;                /* sum of ecs_len                                      */
     uint64_t out_bytes;                /* sum of output sizes                                 */
-    uint64_t coef_bytes;               /* int16 coefficient scratch in HBM                    */
+    uint64_t coef_bytes;               /* coefficient entries + per-unit arrays + dense scratch in HBM */
     uint64_t n_data_units;
     uint64_t n_subsequences;           /* Huffman decode lanes                                */
     uint64_t device_bytes;             /* everything this batch holds in HBM                  */
@@ -131,7 +131,7 @@ typedef struct pjd_batch_info {
     /* diagnostics of the last decode: self-synchronisation effort                           */
     uint64_t sync_rounds;              /* re-sync rounds summed over workgroups               */
     uint64_t sync_lane_passes;         /* lanes that re-decoded their subsequence, summed     */
-    uint64_t fix_rounds, fix_lane_passes;   /* the same for the boundary-stitch kernel        */
+    uint64_t fix_rounds, fix_lane_passes;   /* the same for the boundary-stitch stage          */
 } pjd_batch_info;
 
 /* ---- context --------------------------------------------------------------- */

@@ -32,7 +32,7 @@ struct PjdDevBatch {
     uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
     uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
     const uint32_t *dcblk_image;         // per DC block: owning image
-    unsigned long long *stats;           // [8] diagnostics: 0 sync rounds, 1 lane-passes in sync, 2 fix rounds, 3 lane-passes in fix
+    unsigned long long *stats;           // [16] diagnostics: 0 re-sync rounds (stage A), 1 lane passes in them, 2 / 3 the same for the stitch stage (B)
     uint32_t n_images, n_hwg, n_iwg, n_dcblk;
     uint32_t sub_bytes;                  // Huffman subsequence size of this batch
     uint32_t max_lut_bytes;              // largest PjdDevImage::lut_bytes in the batch (sizes the dynamic LDS of the Huffman kernels)

@@ -1,3 +1,5 @@
+"""GPU diagnostic: which decode route every golden fixture takes (parallel path / exact kernel up front / exact-kernel
+fallback), its subsequence count and the duration of one decode.  Run on an MI355X box: python tools/route_report.py"""
 import sys, os, json
 sys.path.insert(0,'pim-jpeg-decoder_amd/python'); sys.path.insert(0,'tests')
 import pjd_amd, numpy as np
