@@ -7,6 +7,10 @@ One process per GPU (the driver launches N ranks with torch.distributed.run); ev
 OWN batch (weak scaling, no data-path collective: images are independent).  A step = one pass of the
 whole hot path (Huffman entropy decode -> dequantise -> IDCT -> upsample -> YCbCr->RGB) over one
 batch whose bitstreams, tables and work lists are already resident in HBM; pictures stay in HBM.
+By default two identical batches are resident and steps alternate between them, each batch on its own HIP stream
+(`--in-flight 2`), so step i is issued while step i-1 still runs -- a serving loop; every step's results are
+drained and checked (`pjd_batch_sync`) before its batch is decoded again.  `one_batch_in_flight` reports the
+same K steps strictly serialised, and the per-kernel durations / `roofline` come from serialised launches too.
 Rank 0 prints ONE JSON line.  Beside the contract fields it carries `roofline` (dominant kernel: algorithmic
 bytes / HIP-event duration against the HBM peak, PMC traffic from profiles/), `cpu_baseline` (oracle/_ref = the
 reference's own host code on one core, same JPEGs) and, at N=1, `pcie_inclusive`: the same files through the
@@ -99,6 +103,9 @@ def main():
     ap.add_argument("--images", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=8192)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="resident batches decoded round-robin, each on its own HIP stream: step i is issued while step i-1 is "
+                         "still running, as a serving loop would (1 = strictly one step after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check a few pictures against the oracle after the run")
     ap.add_argument("--e2e-batches", type=int, default=16,
@@ -135,14 +142,21 @@ def main():
         for s in scanned:
             s.desc.flags = pjd_amd.F_STANDARD_RESTART
 
-    ctx = pjd_amd.Context(local_rank)          # raises if the HIP library / a gfx950 device is missing
-    batch = ctx.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8)
+    # One context = one HIP stream.  `--in-flight` identical batches are resident; step i decodes batch i % in_flight,
+    # so consecutive steps overlap (the slow tail of one step's entropy decode runs beside the next step's bulk).
+    nfl = max(1, args.in_flight)
+    ctxs = [pjd_amd.Context(local_rank) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing
+    batches = [c.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8) for c in ctxs]
+    ctx, batch = ctxs[0], batches[0]
     t_up = time.perf_counter()
     batch.upload()
     t_up = time.perf_counter() - t_up
+    for b in batches[1:]:
+        b.upload()
     info = batch.info()
     if not args.no_graph:
-        batch.capture()
+        for b in batches:
+            b.capture()
 
     def barrier():
         torch.cuda.synchronize()
@@ -150,20 +164,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.decode()
-        batch.sync()
+    def run_steps(n, group):
+        """n steps round-robin over `group`; every step's decode is drained and its status words read (sync)."""
+        g = len(group)
+        for i in range(n):
+            b = group[i % g]
+            if i >= g:
+                b.sync()              # the step issued g steps ago on this batch: drain, read statuses, redo flagged images
+            b.decode()
+        for b in group[:min(n, g)]:
+            b.sync()
+
+    run_steps(max(args.warmup, nfl), batches)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.decode()
-        batch.sync()          # drains the stream, reads the status words, re-decodes flagged images
+    run_steps(args.steps, batches)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the same K steps strictly one after the other (reported beside `value`, never instead of it)
+    dt_serial = None
+    if nfl > 1:
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps, batches[:1])
+        barrier()
+        dt_serial = time.perf_counter() - t0
     info = batch.info()
 
     # per-kernel durations, HIP events on the library's own stream (ungraphed launches of the same work)
@@ -211,7 +240,7 @@ def main():
             "config": {"workload": f"{args.workload}: {label}", "images_per_gpu": info["n_images"],
                        "pixels_per_gpu": pixels, "ecs_bytes_per_gpu": info["ecs_bytes"],
                        "huffman_lanes": info["n_subsequences"], "exact_kernel_images": info["n_sequential"] + info["n_fallback"],
-                       "hip_graph": not args.no_graph,
+                       "hip_graph": not args.no_graph, "batches_in_flight": nfl,
                        "sync": {k: info[k] for k in ("n_huff_workgroups", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes")}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -220,6 +249,10 @@ def main():
             "kernel_pipeline_ms": round(ktotal, 4),
             "host_ms": {"generate": round(t_gen * 1e3, 1), "scan": round(t_scan * 1e3, 1), "upload": round(t_up * 1e3, 1)},
         }
+        if dt_serial is not None:
+            line["one_batch_in_flight"] = {"value": round(world * pixels * args.steps / dt_serial / 1e6, 2), "unit": "MPix/s",
+                                           "ms_per_step": round(dt_serial / args.steps * 1e3, 4),
+                                           "note": "rank 0's clock, steps strictly one after the other on one stream"}
         if verify is not None:
             line["verified_against_oracle"] = bool(verify)
         if world == 1 and args.e2e_batches > 0:
@@ -238,8 +271,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(jpegs)
         print(json.dumps(line))
-    batch.destroy()
-    ctx.close()
+    for b in batches:
+        b.destroy()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
