@@ -11,7 +11,9 @@
 #define PJD_SUB_BYTES_MAX  1024     //   by the planner (multiple of 64 in this range), see pjd_plan.cpp
 #define PJD_HUFF_THREADS   64       // one wave per Huffman workgroup: lanes exchange states by shuffles, no barriers
 #define PJD_HUFF_OWNED     63       // subsequences owned per workgroup (lane 0 = predecessor overlap)
+#ifndef PJD_NCHK
 #define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into)
+#endif
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
 #define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one image in LDS; larger -> exact kernel

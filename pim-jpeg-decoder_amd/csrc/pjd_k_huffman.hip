@@ -730,7 +730,12 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_onepass(PjdDevBat
 
 // ---------------------------------------------------------------------------------------------
 // tables | checkpoints (state, units-to-come: PJD_NCHK x 64 each) | staged subsequence of the cooperative pass
-static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + 2 * PJD_NCHK * 64 * sizeof(uint32_t) + PJD_SUB_BYTES_MAX + 128; }
+#if PJD_COOP_START_LANES > 0
+#define PJD_COOP_LDS (PJD_SUB_BYTES_MAX + 128)
+#else
+#define PJD_COOP_LDS 0
+#endif
+static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + 2 * PJD_NCHK * 64 * sizeof(uint32_t) + PJD_COOP_LDS; }
 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 {
