@@ -408,3 +408,31 @@ def test_random_streams_one_batch_match_oracle(ctx, port):
             n_seq += 1
     assert info["n_sequential"] == n_seq
     assert info["n_fallback"] == 0
+
+
+def test_two_batches_in_flight_on_two_contexts(port):
+    """bench.py's default mode: two contexts (two HIP streams), decodes issued alternately without waiting for the
+    other one; both produce the oracle's pictures every time."""
+    import pjd_amd
+    names = [n for n in VALID if MANIFEST[n]["huff_ok"]][:24]
+    scanned = [_desc(n) for n in names]
+    want = [port.decode(golden_bytes(n))["rgb"] for n in names]
+    ctxs = [pjd_amd.Context(0), pjd_amd.Context(0)]
+    try:
+        bs = [c.batch([s.desc for s in scanned]) for c in ctxs]
+        for b in bs:
+            b.upload(); b.capture()
+        for step in range(6):
+            b = bs[step % 2]
+            if step >= 2:
+                b.sync()
+            b.decode()
+        for b in bs:
+            outs, st = b.download()
+            assert st == [0] * len(names)
+            for o, w in zip(outs, want):
+                assert np.array_equal(o, w)
+            b.destroy()
+    finally:
+        for c in ctxs:
+            c.close()
