@@ -348,6 +348,8 @@ __device__ __forceinline__ void wave_setup(const PjdDevBatch &B, const PjdDevHuf
 // After the first re-sync round only a few lanes of a wave still have work, and what they have is the
 // worst kind: stretches on which the speculative trajectory never falls into step, so a lane walks a whole
 // subsequence alone at ~580 cycles per symbol -- the chains that decide how long the slowest wave lives.
+// (Measured: ~400 cycles per symbol this way -- a gain, but not the factor hoped for: windows end at every
+// data unit and the scalar walk is ~25 instructions per symbol.)
 // Here the 64 lanes decode the AC symbol that WOULD start at each of the next 64 bit positions (one
 // table look-up each, in parallel), and scalar code then follows the real chain through those candidates
 // with v_readlane: ~10 scalar instructions per symbol instead of a ~70-instruction vector iteration.
@@ -435,10 +437,10 @@ __device__ __forceinline__ int coop_bridge(const uint8_t *tabs, uint32_t tpacked
 
 // A re-sync round that STARTS with at most PJD_COOP_START_LANES active lanes is done cooperatively, one lane after
 // the other; a round in lane-parallel mode hands over when only PJD_COOP_YIELD_LANES lanes are still decoding.
-// Measured (MI355X): a cooperative pass over a 512-byte subsequence takes ~56 us against ~190 us for a lone lane
-// and ~300 us for a lane-parallel round, but passes are serial, so anything above ONE lane loses (1024-image
-// batch, start/yield 1/1: 1.75 ms, 4/1: 2.08, 8/1: 2.24, 16/1: 2.68; single 4K picture 1.16 / 1.39 / 1.82 / 2.16,
-// 1.30 ms without the cooperative pass).
+// Measured (MI355X): a cooperative pass over a whole 512-byte subsequence takes ~140 us (57..144 us per lane observed,
+// depending on where the lane merges) against 190..300 us for a lane-parallel round, but cooperative passes are serial,
+// so anything above ONE lane loses (1024-image batch, start/yield 1/1: 1.75 ms, 4/1: 2.08, 8/1: 2.24, 16/1: 2.68;
+// single 4K picture 1.16 / 1.39 / 1.82 / 2.16, 1.30 ms without the cooperative pass; same ranking with two batches in flight).
 #ifndef PJD_COOP_START_LANES
 #define PJD_COOP_START_LANES 1
 #endif
