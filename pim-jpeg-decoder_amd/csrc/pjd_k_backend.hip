@@ -257,14 +257,18 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
     const uint32_t hs_log = hs - 1, vs_log = vs - 1;
     const uint32_t items = wg.n_mcu << q_log;
     struct __attribute__((packed)) Px12 { uint32_t a, b, c; };
-    for (uint32_t py = tid >> 6; py < mh; py += PJD_IDCT_THREADS / 64) {
-        const uint32_t cy = py >> vs_log, lrow = (py >> 3) * hs, yoff = (py & 7) * 8;
-        for (uint32_t it = tid & 63; it < items; it += 64) {
-            const uint32_t ml = it >> q_log, px0 = (it & ((1u << q_log) - 1)) * 4;
-            const uint32_t xy = mcu_xy[ml];
-            const uint32_t X = __umul24(xy & 0xffffu, mw) + px0, Y = __umul24(xy >> 16, mh) + py;
-            if (X >= width || Y >= height) continue;
-            const uint32_t d0 = __umul24(ml, dus);
+    // item (MCU, 4-pixel column group) outside, picture row inside: everything that depends only on the item
+    // (grid position, X, the unit indices) is computed once per item instead of once per row
+    for (uint32_t it = tid & 63; it < items; it += 64) {
+        const uint32_t ml = it >> q_log, px0 = (it & ((1u << q_log) - 1)) * 4;
+        const uint32_t xy = mcu_xy[ml];
+        const uint32_t X = __umul24(xy & 0xffffu, mw) + px0, Y0 = __umul24(xy >> 16, mh);
+        if (X >= width) continue;
+        const uint32_t d0 = __umul24(ml, dus);
+        for (uint32_t py = tid >> 6; py < mh; py += PJD_IDCT_THREADS / 64) {
+            const uint32_t cy = py >> vs_log, lrow = (py >> 3) * hs, yoff = (py & 7) * 8;
+            const uint32_t Y = Y0 + py;
+            if (Y >= height) continue;
             const int16_t *yp = &tile[d0 + lrow + (px0 >> 3)][yoff + (px0 & 7)];
             const uint2 yraw = *reinterpret_cast<const uint2 *>(yp);               // 4 luma samples
             const int y0 = (int16_t)(yraw.x & 0xffff), y1 = (int16_t)(yraw.x >> 16), y2 = (int16_t)(yraw.y & 0xffff), y3 = (int16_t)(yraw.y >> 16);
