@@ -121,17 +121,25 @@ typedef struct pjd_batch_info {
     uint64_t pixels;                   /* sum of width*height                                 */
     uint64_t ecs_bytes;                /* sum of ecs_len                                      */
     uint64_t out_bytes;                /* sum of output sizes                                 */
-    uint64_t coef_bytes;               /* coefficient entries + per-unit arrays + dense scratch in HBM */
+    uint64_t coef_bytes;               /* lane streams + transposed bitstream words + dense scratch in HBM */
     uint64_t n_data_units;
     uint64_t n_subsequences;           /* Huffman decode lanes                                */
     uint64_t device_bytes;             /* everything this batch holds in HBM                  */
     int32_t  n_sequential;             /* images routed to the exact one-lane kernel up front */
     int32_t  n_fallback;               /* images re-decoded by it after the last decode       */
-    uint64_t n_huff_workgroups;        /* Huffman workgroups (255 lanes each)                 */
+    uint64_t n_huff_workgroups;        /* Huffman workgroups (up to 4 waves of 64 lanes, one table set) */
     /* diagnostics of the last decode: self-synchronisation effort                           */
     uint64_t sync_rounds;              /* re-sync rounds summed over workgroups               */
     uint64_t sync_lane_passes;         /* lanes that re-decoded their subsequence, summed     */
     uint64_t fix_rounds, fix_lane_passes;   /* the same for the boundary-stitch stage          */
+    uint32_t sub_bytes;                /* bytes of bitstream per Huffman lane chosen for this batch */
+    uint32_t n_table_sets;             /* distinct Huffman table sets (images with identical tables share one) */
+    uint64_t n_huff_waves;
+    uint64_t n_entries;                /* 16-bit coefficient entries (= Huffman symbols) emitted by the last decode */
+    uint64_t flag_waves[8];            /* waves that sent their image to the exact kernel in the last decode, by reason:
+                                          0 invalid symbol, 1 irregular segment end / phase, 2 re-sync did not converge,
+                                          3 wave boundary did not stitch, 4 wait timed out, 5 lane output overflow,
+                                          6 write pass did not reproduce the synchronised state                     */
 } pjd_batch_info;
 
 /* ---- context --------------------------------------------------------------- */

@@ -4,7 +4,7 @@
 // reference src/decoder_host.cpp:213-350):
 //   create   plan (pjd_plan.cpp) + allocate HBM and pinned staging
 //   upload   one packed H2D copy of the bitstreams + the small work lists
-//   decode   table build -> one-pass parallel Huffman decode (entry stream) -> DC scan -> fused sparse
+//   decode   table build -> lane words -> parallel Huffman decode (lane streams) -> DC scan over lanes -> fused
 //            IDCT/colour; images routed to the exact kernel: dense scratch -> exact kernel -> dense IDCT/colour
 //   sync     read the status words; any image the parallel decoder flagged is re-decoded by the
 //            exact kernel (on the GPU) and its picture regenerated
@@ -108,24 +108,23 @@ struct pjd_batch {
     PjdDevBatch dev{};
     // owned device allocations (non-const views of what `dev` points to)
     PjdDevImage *d_images = nullptr;
+    PjdDevTset *d_tsets = nullptr;
     PjdDevHuffRaw *d_raw = nullptr;
     uint16_t *d_qtab = nullptr;
     PjdDevSegment *d_segs = nullptr;
-    PjdDevSub *d_subs = nullptr;
+    PjdDevSub *d_lanes = nullptr;
+    PjdDevHuffWave *d_hwaves = nullptr;
     PjdDevHuffWg *d_hwgs = nullptr;
     PjdDevIdctWg *d_iwgs = nullptr;
     PjdDevIdctWg *d_iwgs_dense = nullptr;
     uint8_t *d_ecs = nullptr;
-    uint32_t *d_dcblk_image = nullptr;
-    uint32_t *d_seq_list = nullptr;      // images routed to the exact kernel up front
-    uint32_t *d_fb_list = nullptr;       // scratch list for fallback images
-    PjdDevIdctWg *d_fb_iwgs = nullptr;   // scratch IDCT work list for fallback images
+    uint32_t *d_seq_list = nullptr;      // images routed to the exact kernel up front ...
+    uint64_t *d_seq_base = nullptr;      // ... and where each one's data units start in the dense scratch
     int32_t *d_status_init = nullptr;
-    uint64_t *d_opstate = nullptr;       // wg_exit + wg_desc + ticket
+    uint64_t *d_opstate = nullptr;       // wave_gen + wave_desc + ticket
     size_t opstate_bytes = 0;
     uint8_t *h_ecs = nullptr;            // pinned staging
     int32_t *h_status = nullptr;         // pinned
-    std::vector<uint32_t> iwg_base, iwg_count;   // per image, into plan.iwgs
     std::vector<uint32_t> seq_list;      // what d_seq_list holds
     std::vector<PoolBlock> dev_blocks, pin_blocks;   // everything this batch took from the context's pools
     uint64_t device_bytes = 0;
@@ -239,14 +238,6 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     }
     if (pool_pin_alloc(ctx, (void **)&b->h_status, sizeof(int32_t) * (n_images + 1), b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
 
-    // per-image IDCT work-list ranges (for the fallback re-run)
-    b->iwg_base.assign(n_images, 0); b->iwg_count.assign(n_images, 0);
-    for (size_t k = 0; k < P.iwgs.size(); k++) {
-        uint32_t im = P.iwgs[k].image;
-        if (b->iwg_count[im] == 0) b->iwg_base[im] = (uint32_t)k;
-        b->iwg_count[im]++;
-    }
-
     uint64_t &tot = b->device_bytes;
 #define TRY_RC(x) do { int rc_ = (x); if (rc_ != PJD_OK) return fail(rc_); } while (0)
     auto dev_alloc = [&](pjd_ctx *c, auto *&dptr, size_t n, uint64_t &total) {
@@ -258,46 +249,50 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
         total += n * sizeof(T);
         return r;
     };
+    const size_t n_hwave = P.hwaves.size();
     TRY_RC(dev_alloc(ctx, b->d_images, P.images.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_tsets, P.tsets.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_raw, P.tables.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_qtab, P.qtab.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_segs, P.segs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_subs, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_lanes, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->d_hwaves, n_hwave, tot));
     TRY_RC(dev_alloc(ctx, b->d_hwgs, P.hwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_iwgs, P.iwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_iwgs_dense, P.iwgs_dense.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_fb_iwgs, P.iwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->d_ecs, P.ecs_buf_bytes, tot));
-    TRY_RC(dev_alloc(ctx, b->d_dcblk_image, P.n_dcblk, tot));
     TRY_RC(dev_alloc(ctx, b->d_seq_list, (size_t)n_images, tot));
-    TRY_RC(dev_alloc(ctx, b->d_fb_list, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->d_seq_base, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->d_status_init, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->dev.luts, (size_t)P.lut_buf_bytes, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.words, (size_t)P.n_words, tot));
     TRY_RC(dev_alloc(ctx, b->dev.coef, P.dense_du * 64, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.ent, P.n_ent, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.du_end, P.n_du, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.seg_ent, P.segs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.dcv, P.n_du, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.ent, (size_t)P.n_ent, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.lane_info, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.lane_dc, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.dc_blk, (size_t)P.n_dcblk * 8, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.marks, P.iwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.out, P.out_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
-    // wg_exit [2][n_hwg], wg_desc [n_hwg] and the ticket live in one allocation, zeroed before every launch
-    TRY_RC(dev_alloc(ctx, b->d_opstate, P.hwgs.size() * 3 + 2, tot));
-    b->opstate_bytes = (P.hwgs.size() * 3 + 2) * sizeof(uint64_t);
-    b->dev.wg_exit = b->d_opstate;
-    b->dev.wg_desc = b->d_opstate + P.hwgs.size() * 2;
-    b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + P.hwgs.size() * 3);
+    // wave_gen [3][n_hwave], wave_desc [n_hwave] and the ticket live in one allocation, zeroed before every launch
+    TRY_RC(dev_alloc(ctx, b->d_opstate, n_hwave * 4 + 2, tot));
+    b->opstate_bytes = (n_hwave * 4 + 2) * sizeof(uint64_t);
+    b->dev.wave_gen = b->d_opstate;
+    b->dev.wave_desc = b->d_opstate + n_hwave * 3;
+    b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + n_hwave * 4);
     b->dev.dbg = nullptr;
-    if (std::getenv("PJD_DEBUG_STATS")) TRY_RC(dev_alloc(ctx, b->dev.dbg, P.hwgs.size() * 32, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.dc_agg, P.n_dcblk * 4, tot));
-    TRY_RC(dev_alloc(ctx, b->dev.dc_carry, P.n_dcblk * 4, tot));
+    if (std::getenv("PJD_DEBUG_STATS")) TRY_RC(dev_alloc(ctx, b->dev.dbg, n_hwave * 32, tot));
     TRY_RC(dev_alloc(ctx, b->dev.stats, 16, tot));
 #undef TRY_RC
-    b->dev.images = b->d_images; b->dev.raw_tables = b->d_raw; b->dev.qtab = b->d_qtab;
-    b->dev.segs = b->d_segs; b->dev.subs = b->d_subs; b->dev.hwgs = b->d_hwgs; b->dev.iwgs = b->d_iwgs;
-    b->dev.ecs = b->d_ecs; b->dev.dcblk_image = b->d_dcblk_image;
-    b->dev.n_images = (uint32_t)n_images; b->dev.n_hwg = (uint32_t)P.hwgs.size();
+    b->dev.images = b->d_images; b->dev.tsets = b->d_tsets; b->dev.raw_tables = b->d_raw; b->dev.qtab = b->d_qtab;
+    b->dev.segs = b->d_segs; b->dev.lanes = b->d_lanes; b->dev.hwaves = b->d_hwaves; b->dev.hwgs = b->d_hwgs; b->dev.iwgs = b->d_iwgs;
+    b->dev.ecs = b->d_ecs;
+    b->dev.n_images = (uint32_t)n_images; b->dev.n_tsets = (uint32_t)P.tsets.size(); b->dev.n_lanes = (uint32_t)P.subs.size();
+    b->dev.n_hwave = (uint32_t)n_hwave; b->dev.n_hwg = (uint32_t)P.hwgs.size();
     b->dev.n_iwg = (uint32_t)P.iwgs.size(); b->dev.n_dcblk = (uint32_t)P.n_dcblk;
     b->dev.sub_bytes = P.sub_bytes;
+    b->dev.word_rows = PJD_WORD_ROWS(P.sub_bytes);
+    b->dev.lane_cap = PJD_LANE_CAP(P.sub_bytes);
     b->dev.max_lut_bytes = P.max_lut_bytes;
     *out = b;
     return PJD_OK;
@@ -311,17 +306,16 @@ int pjd_batch_upload(pjd_batch *b)
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
 #define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(ctx, hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, s)); } while (0)
-    UP(b->d_images, P.images); UP(b->d_raw, P.tables); UP(b->d_qtab, P.qtab);
-    UP(b->d_segs, P.segs); UP(b->d_subs, P.subs); UP(b->d_hwgs, P.hwgs); UP(b->d_iwgs, P.iwgs); UP(b->d_iwgs_dense, P.iwgs_dense);
-    std::vector<uint32_t> dcimg(P.n_dcblk);
-    for (size_t i = 0; i < P.images.size(); i++)
-        for (uint32_t k = 0; k < P.images[i].n_dcblk; k++) dcimg[P.images[i].dcblk_base + k] = (uint32_t)i;
-    UP(b->d_dcblk_image, dcimg);
-    // routing: images for the exact kernel, and the initial status words
+    UP(b->d_images, P.images); UP(b->d_tsets, P.tsets); UP(b->d_raw, P.tables); UP(b->d_qtab, P.qtab);
+    UP(b->d_segs, P.segs); UP(b->d_lanes, P.subs); UP(b->d_hwaves, P.hwaves); UP(b->d_hwgs, P.hwgs);
+    UP(b->d_iwgs, P.iwgs); UP(b->d_iwgs_dense, P.iwgs_dense);
+    // routing: images for the exact kernel (with their place in the dense scratch), and the initial status words
     b->seq_list = P.seq_images;
+    std::vector<uint64_t> seq_base;
     std::vector<int32_t> st0(P.images.size(), 0);
-    for (uint32_t i : b->seq_list) st0[i] = PJD_STW_NEEDS_EXACT;
+    for (uint32_t i : b->seq_list) { st0[i] = PJD_STW_NEEDS_EXACT; seq_base.push_back(P.images[i].dense_base); }
     UP(b->d_seq_list, b->seq_list);
+    UP(b->d_seq_base, seq_base);
     UP(b->d_status_init, st0);
 #undef UP
     HIP_TRY(ctx, hipMemcpyAsync(b->d_ecs, b->h_ecs, P.ecs_buf_bytes, hipMemcpyHostToDevice, s));
@@ -383,23 +377,22 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     kt.mark("start");
     HIP_TRY(ctx, hipMemcpyAsync(b->dev.status, b->d_status_init, sizeof(int32_t) * P.images.size(), hipMemcpyDeviceToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(b->dev.stats, 0, 16 * sizeof(unsigned long long), s));
-    if (b->dev.dbg) HIP_TRY(ctx, hipMemsetAsync(b->dev.dbg, 0, P.hwgs.size() * 32 * sizeof(uint32_t), s));
+    if (b->dev.dbg) HIP_TRY(ctx, hipMemsetAsync(b->dev.dbg, 0, P.hwaves.size() * 32 * sizeof(uint32_t), s));
+    if (parallel) HIP_TRY(ctx, hipMemsetAsync(b->d_opstate, 0, b->opstate_bytes, s));
     kt.mark("reset");
     if (parallel) {
         pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
-        HIP_TRY(ctx, hipMemsetAsync(b->d_opstate, 0, b->opstate_bytes, s));
-        pjd_launch_huff_onepass(s, b->dev);  kt.mark("huff_onepass");
-        pjd_launch_dc_scan(s, b->dev);       kt.mark("dc_scan");
-        pjd_launch_idct_colour_sparse(s, b->dev, b->d_iwgs, (uint32_t)P.iwgs.size());
+        pjd_launch_lane_words(s, b->dev);    kt.mark("lane_words");
+        pjd_launch_huff_lanes(s, b->dev);    kt.mark("huff_lanes");
+        pjd_launch_lane_dc_scan(s, b->dev);  kt.mark("dc_scan");
+        pjd_launch_idct_colour_lanes(s, b->dev);
         kt.mark("idct_colour");
     }
     if (!b->seq_list.empty()) {
         // images routed to the exact kernel: dense int16 scratch, cleared first (unvisited slots are zero)
-        uint64_t seq_du = 0;
-        for (uint32_t i : b->seq_list) seq_du += P.images[i].n_du;
-        HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, seq_du * 64 * sizeof(int16_t), s));
-        pjd_launch_huff_sequential(s, b->dev, b->d_seq_list, (uint32_t)b->seq_list.size());
-        pjd_launch_idct_colour(s, b->dev, b->d_iwgs_dense, (uint32_t)P.iwgs_dense.size());
+        HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, P.dense_du * 64 * sizeof(int16_t), s));
+        pjd_launch_huff_sequential(s, b->dev, b->d_seq_list, b->d_seq_base, (uint32_t)b->seq_list.size());
+        pjd_launch_idct_colour(s, b->dev, b->d_iwgs_dense, b->d_seq_base, (uint32_t)P.iwgs_dense.size());
         kt.mark("exact_path");
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -410,7 +403,10 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
 }
 
 // After the stream drained: re-decode, with the exact kernel, every image the parallel decoder
-// flagged.  Runs on the GPU; the coefficient range of such an image is cleared first.
+// flagged -- all of them in ONE launch, into a dense scratch allocated for just them (a rare path: corrupt
+// or otherwise irregular streams).  Runs on the GPU.  A shard is re-decoded over its own segment range.
+// As in the reference (decoder_host.cpp:181 drops decode_Huffman_data's result) such an image keeps its status
+// and its partial picture; the rest of the batch is unaffected.
 int settle(pjd_batch *b)
 {
     pjd_ctx *ctx = b->ctx;
@@ -421,27 +417,48 @@ int settle(pjd_batch *b)
     HIP_TRY(ctx, hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     std::vector<uint32_t> fb;
+    std::vector<uint64_t> fb_base;
+    std::vector<PjdDevIdctWg> fb_wgs;
     std::vector<char> was_seq(n, 0);
     for (uint32_t i : b->seq_list) was_seq[i] = 1;
+    uint64_t du = 0;
     for (size_t i = 0; i < n; i++)
-        if ((b->h_status[i] & PJD_STW_NEEDS_EXACT) && !was_seq[i]) fb.push_back((uint32_t)i);
-    b->n_fallback = (int)fb.size();
-    for (uint32_t i : fb) {
-        // one image at a time through the shared dense scratch (stream order keeps them apart)
-        if (P.images[i].first_mcu != 0 || P.images[i].last_mcu != P.images[i].n_mcu) {
-            ctx->err = "a sharded image needs the exact kernel (irregular restart segment)";
-            return PJD_E_ARG;
+        if ((b->h_status[i] & PJD_STW_NEEDS_EXACT) && !was_seq[i]) {
+            const PjdDevImage &g = P.images[i];
+            for (uint32_t k = 0; k < g.n_iwg; k++) {
+                PjdDevIdctWg w = P.iwgs[g.iwg_base + k];
+                w.pad_ = (uint32_t)fb.size();
+                fb_wgs.push_back(w);
+            }
+            fb.push_back((uint32_t)i);
+            fb_base.push_back(du);
+            du += (uint64_t)(g.last_mcu - g.first_mcu) * g.dus_per_mcu;
         }
-        HIP_TRY(ctx, hipMemsetAsync(b->dev.coef + P.images[i].dense_base * 64, 0, (size_t)P.images[i].n_du * 64 * sizeof(int16_t), s));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_fb_list, &i, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));      // `i` is a stack variable
-        pjd_launch_huff_sequential(s, b->dev, b->d_fb_list, 1);
-        pjd_launch_idct_colour(s, b->dev, b->d_iwgs + b->iwg_base[i], b->iwg_count[i]);
-        HIP_TRY(ctx, hipGetLastError());
-    }
+    b->n_fallback = (int)fb.size();
     if (!fb.empty()) {
-        HIP_TRY(ctx, hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        int16_t *coef = nullptr; uint32_t *d_list = nullptr; uint64_t *d_base = nullptr; PjdDevIdctWg *d_wgs = nullptr;
+        auto cleanup = [&] { hipFree(coef); hipFree(d_list); hipFree(d_base); hipFree(d_wgs); };
+        if (hipMalloc((void **)&coef, du * 64 * sizeof(int16_t)) != hipSuccess || hipMalloc((void **)&d_list, fb.size() * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&d_base, fb.size() * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&d_wgs, fb_wgs.size() * sizeof(PjdDevIdctWg)) != hipSuccess) {
+            cleanup();
+            ctx->err = "hipMalloc failed for the exact-kernel scratch";
+            return PJD_E_NOMEM;
+        }
+        PjdDevBatch dv = b->dev;
+        dv.coef = coef;
+        hipError_t e = hipMemsetAsync(coef, 0, du * 64 * sizeof(int16_t), s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_list, fb.data(), fb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_base, fb_base.data(), fb_base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_wgs, fb_wgs.data(), fb_wgs.size() * sizeof(PjdDevIdctWg), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            pjd_launch_huff_sequential(s, dv, d_list, d_base, (uint32_t)fb.size());
+            pjd_launch_idct_colour(s, dv, d_wgs, d_base, (uint32_t)fb_wgs.size());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);        // also: the host vectors above are pageable
+        cleanup();
+        if (e != hipSuccess) { ctx->err = std::string("exact-kernel fallback: ") + hipGetErrorString(e); return PJD_E_HIP; }
     }
     b->settled = true;
     return PJD_OK;
@@ -504,6 +521,7 @@ int pjd_batch_download(pjd_batch *b, uint8_t *const *out, int32_t *status)
 {
     if (!b) return PJD_E_ARG;
     if (!b->decoded) { b->ctx->err = "download before decode"; return PJD_E_STATE; }
+    hipSetDevice(b->ctx->device);
     int rc = settle(b);
     if (rc != PJD_OK) return rc;
     pjd_ctx *ctx = b->ctx;
@@ -555,46 +573,60 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
 {
     if (!b || !info) return PJD_E_ARG;
     PjdPlan &P = b->plan;
+    hipSetDevice(b->ctx->device);
     std::memset(info, 0, sizeof *info);
     info->n_images = (int32_t)P.images.size();
     info->pixels = P.pixels; info->ecs_bytes = P.ecs_bytes; info->out_bytes = P.out_bytes;
-    info->coef_bytes = P.n_ent * 4 + P.n_du * 6 + P.dense_du * 128;
+    info->coef_bytes = P.n_ent * 2 + P.n_words * 4 + P.dense_du * 128;
     info->n_data_units = P.n_du;
     info->n_subsequences = P.subs.size();
     info->device_bytes = b->device_bytes;
     info->n_sequential = (int32_t)b->seq_list.size();
     info->n_fallback = b->n_fallback;
+    info->sub_bytes = P.sub_bytes;
+    info->n_table_sets = (uint32_t)P.tsets.size();
+    info->n_huff_waves = P.hwaves.size();
     unsigned long long st[16] = {0};
     if (b->decoded && hipMemcpy(st, b->dev.stats, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
         info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
+        for (int r = 0; r < PJD_FLAG_REASONS && r < 8; r++) info->flag_waves[r] = st[PJD_STAT_FLAG0 + r];
     }
     info->n_huff_workgroups = P.hwgs.size();
+    if (b->decoded && !P.subs.empty()) {                      // entries the lanes emitted in the last decode
+        std::vector<PjdDevLaneInfo> li(P.subs.size());
+        if (hipMemcpy(li.data(), b->dev.lane_info, li.size() * sizeof(PjdDevLaneInfo), hipMemcpyDeviceToHost) == hipSuccess)
+            for (const PjdDevLaneInfo &x : li) info->n_entries += x.n_ent;
+    }
     if (b->dev.dbg && b->decoded) {          // PJD_DEBUG_STATS: wave timeline of the last decode (units of 10 ns)
-        std::vector<uint32_t> d(P.hwgs.size() * 32);
-        if (hipMemcpy(d.data(), b->dev.dbg, d.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && !P.hwgs.empty()) {
+        const size_t nw = P.hwaves.size();
+        std::vector<uint32_t> d(nw * 32);
+        if (hipMemcpy(d.data(), b->dev.dbg, d.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && nw) {
             uint32_t t0 = d[0];
-            for (size_t k = 0; k < P.hwgs.size(); k++) if ((int32_t)(d[k * 32] - t0) < 0) t0 = d[k * 32];
+            for (size_t k = 0; k < nw; k++) if ((int32_t)(d[k * 32] - t0) < 0) t0 = d[k * 32];
             double sum[6] = {0}; uint32_t mx[6] = {0}; size_t worst = 0; uint32_t worst_end = 0;
-            for (size_t k = 0; k < P.hwgs.size(); k++) {
+            for (size_t k = 0; k < nw; k++) {
                 const uint32_t *e = &d[k * 32];
                 uint32_t end = e[0] - t0;
                 for (int q = 1; q <= 5; q++) { sum[q] += e[q]; if (e[q] > mx[q]) mx[q] = e[q]; end += e[q]; }
                 sum[0] += e[0] - t0; if (e[0] - t0 > mx[0]) mx[0] = e[0] - t0;
                 if (end > worst_end) { worst_end = end; worst = k; }
             }
-            const double n = (double)P.hwgs.size();
-            std::fprintf(stderr, "[pjd waves] n %zu | mean(us): start %.1f round0 %.1f roundsA %.1f stitch %.1f scan %.1f write+verify %.1f | max(us): %.1f %.1f %.1f %.1f %.1f %.1f\n",
-                         P.hwgs.size(), sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, sum[4] / n / 100, sum[5] / n / 100,
+            const double n = (double)nw;
+            std::fprintf(stderr, "[pjd waves] n %zu | mean(us): start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write+verify %.1f | max(us): %.1f %.1f %.1f %.1f %.1f %.1f\n",
+                         nw, sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, sum[4] / n / 100, sum[5] / n / 100,
                          mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0, mx[4] / 100.0, mx[5] / 100.0);
             const uint32_t *e = &d[worst * 32];
-            std::fprintf(stderr, "[pjd waves] last to finish: wave %zu (image %u, %u subs) start %.1f round0 %.1f roundsA %.1f stitch %.1f scan %.1f write %.1f -> end %.1f us\n",
+            std::fprintf(stderr, "[pjd waves] last to finish: wave %zu (image %u, %u lanes) start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write %.1f -> end %.1f us\n",
                          worst, e[6], e[7], (e[0] - t0) / 100.0, e[1] / 100.0, e[2] / 100.0, e[3] / 100.0, e[4] / 100.0, e[5] / 100.0, worst_end / 100.0);
             // the waves of that image
-            for (size_t k = 0; k < P.hwgs.size(); k++)
-                if (d[k * 32 + 6] == e[6])
-                    std::fprintf(stderr, "[pjd waves]   wave %zu: start %.1f round0 %.1f roundsA %.1f stitch %.1f scan %.1f write %.1f\n", k,
-                                 (d[k * 32] - t0) / 100.0, d[k * 32 + 1] / 100.0, d[k * 32 + 2] / 100.0, d[k * 32 + 3] / 100.0, d[k * 32 + 4] / 100.0, d[k * 32 + 5] / 100.0),
-                    [&] { std::fprintf(stderr, "[pjd waves]     rounds (lanes:us):"); for (int r = 0; r < 24 && d[k * 32 + 8 + r]; r++) std::fprintf(stderr, " %u:%.1f", d[k * 32 + 8 + r] >> 24, (d[k * 32 + 8 + r] & 0xffffff) / 100.0); std::fprintf(stderr, "\n"); }();
+            for (size_t k = 0; k < nw; k++)
+                if (d[k * 32 + 6] == e[6] && d[k * 32 + 7] != 0) {
+                    std::fprintf(stderr, "[pjd waves]   wave %zu: start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write %.1f\n", k,
+                                 (d[k * 32] - t0) / 100.0, d[k * 32 + 1] / 100.0, d[k * 32 + 2] / 100.0, d[k * 32 + 3] / 100.0, d[k * 32 + 4] / 100.0, d[k * 32 + 5] / 100.0);
+                    std::fprintf(stderr, "[pjd waves]     rounds (lanes:us):");
+                    for (int r = 0; r < 24 && d[k * 32 + 8 + r]; r++) std::fprintf(stderr, " %u:%.1f", d[k * 32 + 8 + r] >> 24, (d[k * 32 + 8 + r] & 0xffffff) / 100.0);
+                    std::fprintf(stderr, "\n");
+                }
         }
     }
     return PJD_OK;
@@ -614,6 +646,10 @@ int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pj
     info->n_data_units = P.n_du;
     info->n_subsequences = P.subs.size();
     info->n_sequential = (int32_t)P.seq_images.size();
+    info->sub_bytes = P.sub_bytes;
+    info->n_table_sets = (uint32_t)P.tsets.size();
+    info->n_huff_waves = P.hwaves.size();
+    info->n_huff_workgroups = P.hwgs.size();
     return PJD_OK;
 }
 

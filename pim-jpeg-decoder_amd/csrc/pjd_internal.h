@@ -9,20 +9,39 @@
 // ---- tunables -----------------------------------------------------------------
 #define PJD_SUB_BYTES_MIN  128      // Huffman subsequence (bytes of bitstream per decode lane): chosen per batch
 #define PJD_SUB_BYTES_MAX  1024     //   by the planner (multiple of 64 in this range), see pjd_plan.cpp
-#define PJD_HUFF_THREADS   64       // one wave per Huffman workgroup: lanes exchange states by shuffles, no barriers
-#define PJD_HUFF_OWNED     63       // subsequences owned per workgroup (lane 0 = predecessor overlap)
-#ifndef PJD_NCHK
+#define PJD_HUFF_LANES     64       // subsequences per wave: lanes exchange states by shuffles, no barriers
+#define PJD_HUFF_WAVES     4        // waves per Huffman workgroup; they share one table set in LDS
+#define PJD_HUFF_THREADS   (PJD_HUFF_LANES * PJD_HUFF_WAVES)
 #define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into)
-#endif
+#define PJD_WAVE_LDS       (2 * PJD_NCHK * 64 * 4)   // per wave: checkpoints (sync passes) / entry staging (write pass)
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
-#define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one image in LDS; larger -> exact kernel
+#define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one table set in LDS; larger -> exact kernel
 #define PJD_MAX_TABLES     6        // distinct Huffman tables one image can reference (3 DC + 3 AC)
-#define PJD_SYNC_MAX_ITERS 24       // re-sync rounds per wave before giving up (-> exact fallback)
-#define PJD_DC_BLOCK       256      // MCUs per DC-prediction scan block
+#define PJD_SYNC_MAX_ITERS 72       // re-sync rounds per wave before giving up (a non-merging chain moves one lane per round)
+#define PJD_DC_BLOCK       256      // lanes per DC-prediction scan block
 #define PJD_IDCT_THREADS   256
 #define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup
 #define PJD_COEF_SENTINEL  (-32768) // "slot 52 was visited with an explicit 0" (zigzag quirk)
+
+// Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
+// the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
+#define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
+// Entries (2 bytes, one per decoded symbol) a lane may emit into its own region; a lane that would need more
+// (< 2 bits per symbol on average) flags its image for the exact kernel.
+#define PJD_LANE_CAP(sub_bytes)   (4 * (sub_bytes) + 64)
+#define PJD_STAGE_ENTRIES  (PJD_WAVE_LDS / 64 / 2)       // entries a lane stages in LDS between flushes (32)
+
+// ---- coefficient entries (lane streams) --------------------------------------------------------
+// The write pass turns every decoded Huffman symbol into exactly one 16-bit entry:
+//   DC symbol            bits 10..0 = diff[10:0], bit 12 = diff[11], bit 11 = 0, other bits 0   (12-bit two's complement)
+//   AC run/size symbol   bits 15..12 = run, bit 11 = "unit complete" (this coefficient lands on slot 63),
+//                        bits 10..0 = value (11-bit two's complement; 0 for a size-0 symbol such as ZRL)
+//   EOB                  0x0800: run 0, value 0, "unit complete"
+// A unit is [DC][AC ...] up to and including the first entry with bit 11 set; the slot of an AC entry is the
+// running sum of (run + 1) over the unit.  A size-0 symbol stores an explicit 0 (reference
+// src/jpeg_scanner.cpp:516-517), which matters at slot 52 only (zigzag quirk).
+#define PJD_ENT_LAST       0x0800u
 
 // ---- image flags (device side) -----------------------------------------------------
 #define PJD_IF_STANDARD_RESTART 1u  // restart every RI-th MCU; else the reference's (y*Wr+x)%RI rule
@@ -31,6 +50,19 @@
 
 // status word per image: low 8 bits = PJD_ST_* class, bit 8 = "fast path gave up, needs exact kernel"
 #define PJD_STW_NEEDS_EXACT 0x100
+
+// why the parallel decoder flagged an image (PjdDevBatch::stats[PJD_STAT_FLAG0 + reason], counted per wave)
+enum {
+    PJD_FLAG_SYMBOL = 0,     // invalid code, size or run outside the baseline limits
+    PJD_FLAG_SEGMENT,        // a restart segment ends early / late / off a byte boundary, phase or count mismatch
+    PJD_FLAG_NOSYNC,         // re-sync rounds did not converge within PJD_SYNC_MAX_ITERS
+    PJD_FLAG_STITCH,         // the entry a wave used is not what its predecessor finally produced
+    PJD_FLAG_TIMEOUT,        // a bounded wait on another wave expired, or that wave was poisoned
+    PJD_FLAG_OVERFLOW,       // a lane needed more than PJD_LANE_CAP entries
+    PJD_FLAG_VERIFY,         // the write pass did not reproduce the synchronised exit state / unit count
+    PJD_FLAG_REASONS
+};
+#define PJD_STAT_FLAG0 4
 
 struct PjdDevImage {
     uint32_t width, height;
@@ -43,28 +75,20 @@ struct PjdDevImage {
     uint32_t ref_mcu_w, ref_mcu_h, ref_mcu_w_real;   // reference Header::mcu_width / mcu_height / mcu_width_real
     uint32_t ecs_len;                  // bytes
     uint64_t ecs_off;                  // into the batch bitstream buffer (16-byte aligned)
-    uint64_t du_base;                  // first data unit of this image in the per-unit arrays (dcv, and du_off at du_base + image index)
-    uint64_t ent_base;                 // first entry of this image in the coefficient-entry stream
     uint64_t dense_base;               // first data unit of this image in the DENSE scratch (exact-kernel path only)
     uint32_t n_du;
     uint32_t image_index;
     uint32_t out_stride;               // bytes per output row (BMP: 3W + W%4, RGB8: 3W)
     uint64_t out_off;                  // into the batch output buffer (256-byte aligned)
     uint32_t seg_base, n_seg;          // into PjdDevSegment[]
-    uint32_t sub_base, n_sub;          // into PjdDevSub[]
-    uint32_t hwg_base, n_hwg;          // Huffman workgroups of this image
-    uint32_t dcblk_base, n_dcblk;      // DC scan blocks of this image
+    uint32_t lane_base, n_lane;        // into PjdDevSub[] (global lane index)
+    uint32_t hwave_base, n_hwave;      // Huffman waves of this image (global wave index)
+    uint32_t iwg_base, n_iwg;          // IDCT workgroups (= coefficient ranges) of this image
+    uint32_t idct_mcus;                // MCUs per IDCT workgroup
     uint32_t first_mcu, last_mcu;      // MCU range this shard decodes: [first_mcu, last_mcu)
-    uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1
-    uint8_t  n_tables;
-    uint8_t  pad_[1];
-    // decode tables of this image inside PjdDevBatch::luts (layout: see "decode-ready tables" below)
-    uint32_t lut_off16;                // blob offset in 16-byte units
-    uint32_t lut_bytes;                // multiple of 16; 0 for images routed to the exact kernel
-    uint16_t l2_off[PJD_MAX_TABLES];   // second-level region of table k: first u16 index, relative to the image's blob
-    uint16_t l2_p0[PJD_MAX_TABLES];    // 10-bit prefixes [p0, p1) hold codes longer than PJD_LUT_BITS
-    uint16_t l2_p1[PJD_MAX_TABLES];
-    uint16_t pad2_[2];
+    uint32_t tset;                     // table set (PjdDevTset) of this image
+    uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1 of the set
+    uint8_t  pad_[2];
 };
 
 // raw Huffman table as shipped by the host (reference HuffmanTable, jpeg.h:129-134)
@@ -74,16 +98,33 @@ struct PjdDevHuffRaw {
     uint8_t is_ac;
 };                                     // 180 bytes
 
-// decode-ready tables, built on the device by pjd_k_build_tables.  One blob per image:
+// One table set = the deduplicated Huffman tables of an image; images with identical sets share one (a batch of
+// files written with the Annex-K tables has a single set), and so can the waves of one Huffman workgroup.
+// Decode-ready form, built on the device by pjd_k_build_tables, one blob per set:
 //   [table 0 L1][table 1 L1]...[table n-1 L1][second-level regions, 64 u16 per long prefix]
 // L1 is indexed by the next PJD_LUT_BITS bits.  Entry (u16):
-//   bit 15 = 0 : (length << 8) | symbol, length 1..10;  bit 14 set = no code starts with these bits
-//                (then length = 16, symbol = 0: what the reference's get_next_symbol consumes before failing)
+//   bit 15 = 0 : bits 4..0 = bits consumed by the symbol (code length + size), bits 8..5 = run, bits 12..9 = size,
+//                bit 13 = EOB (AC tables only), bit 14 = error (no code starts with these bits: consume 16 as the
+//                reference's get_next_symbol does; DC size > 11; AC size > 10)
 //   bit 15 = 1 : codes with this prefix are longer than 10 bits; bits 14..0 = u16 index (relative to the blob)
 //                of the prefix's 64-entry second-level table, indexed by the following 6 bits; entries there
-//                have the first form with length 11..16.
+//                have the first form with code lengths 11..16.
 // Canonical codes keep all long codes in one contiguous range of prefixes [p0, p1), so the second level
 // costs 128 bytes per long prefix (Annex K tables: 5 prefixes for an AC table, 0..1 for a DC table).
+struct PjdDevTset {
+    uint32_t lut_off16;                // blob offset in PjdDevBatch::luts, 16-byte units
+    uint32_t lut_bytes;                // multiple of 16
+    uint32_t n_tables;
+    uint16_t l2_off[PJD_MAX_TABLES];   // second-level region of table k: first u16 index, relative to the blob
+    uint16_t l2_p0[PJD_MAX_TABLES];    // 10-bit prefixes [p0, p1) hold codes longer than PJD_LUT_BITS
+    uint16_t l2_p1[PJD_MAX_TABLES];
+};
+#define PJD_LUT_USED(e)  ((e) & 31u)
+#define PJD_LUT_RUN(e)   (((e) >> 5) & 15u)
+#define PJD_LUT_SIZE(e)  (((e) >> 9) & 15u)
+#define PJD_LUT_EOB      0x2000u
+#define PJD_LUT_ERR      0x4000u
+#define PJD_LUT_L2       0x8000u
 
 struct PjdDevSegment {                 // one restart segment
     uint32_t byte_start;               // relative to the image's ecs
@@ -97,18 +138,48 @@ struct PjdDevSub {                     // one Huffman subsequence (decode lane)
     uint32_t seg;                      // global segment index | (1u<<31 if first subsequence of its segment)
 };
 
-struct PjdDevHuffWg {                  // one Huffman workgroup
+struct PjdDevHuffWave {                // one Huffman wave: up to 64 consecutive lanes of one image
     uint32_t image;
-    uint32_t first_sub;                // global subsequence index of the first OWNED subsequence
-    uint32_t n_sub;                    // owned, 1..PJD_HUFF_OWNED
+    uint32_t first_lane;               // global lane index
+    uint32_t n_lanes;                  // 1..64
     uint32_t pad_;
 };
 
-struct PjdDevIdctWg {                  // one IDCT/colour workgroup
+struct PjdDevHuffWg {                  // one Huffman workgroup: up to PJD_HUFF_WAVES consecutive waves of one table set
+    uint32_t first_wave;
+    uint32_t n_waves;
+    uint32_t tset;
+    uint32_t pad_;
+};
+
+struct PjdDevIdctWg {                  // one IDCT/colour workgroup = one coefficient range
     uint32_t image;
     uint32_t first_mcu;
     uint32_t n_mcu;
     uint32_t pad_;
+};
+
+// what a Huffman lane leaves behind for the back end (written at the end of its write pass)
+struct PjdDevLaneInfo {
+    uint32_t n_ent;                    // entries in the lane's region
+    uint32_t seg_first;                // 1: the lane starts a restart segment (DC predictors are zero there)
+    uint16_t dc_sum[3];                // sum of the DC differences decoded in this lane, per component (mod 2^16)
+    uint16_t pad_;
+};
+
+// DC predictors at the start of a lane, from the scan over PjdDevLaneInfo::dc_sum (pjd_k_lane_dc_*)
+struct PjdDevLaneDc {
+    uint16_t dc_in[3];                 // relative to the start of the lane's scan block, or absolute if `abs`
+    uint16_t abs;                      // 1: a segment head lies between the block start and this lane
+};
+
+// where an IDCT workgroup's first data unit starts in the lane streams (written by the lane that decodes
+// that unit's DC symbol)
+struct PjdDevMark {
+    uint32_t lane;                     // global lane index
+    uint32_t ent_off;                  // entry index inside the lane's region
+    uint16_t acc[3];                   // DC differences summed over this lane up to (not including) that unit
+    uint16_t pad_;
 };
 
 // packed decoder state at a subsequence boundary: bit position (relative to the

@@ -85,41 +85,21 @@ void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mc
 }
 
 // ---------------------------------------------------------------------------------------------
-// DC prediction.  After the parallel entropy decode, dcv[] holds the DC DIFFERENCE of every data
-// unit.  Level 1: each workgroup takes PJD_DC_BLOCK MCUs of one image, scans the
-// per-component sums with resets at restart points, and rewrites slot 0 with the prediction
-// relative to the block start.  Level 2: one wave per image scans the block aggregates.  The
-// IDCT kernel adds the carry.  All sums are modulo 2^16 like the reference's `short` stores.
+// DC prediction.  The entropy decoder emits DC DIFFERENCES and, per lane, their sum per component.
+// The predictors at the start of every lane are a segmented scan over lanes (a lane that starts a
+// restart segment resets them, reference src/jpeg_scanner.cpp:485-486,723-727), done in two levels:
+// blocks of PJD_DC_BLOCK lanes, then one workgroup over the block aggregates.  The back end adds
+// the block's carry-in itself.  All sums are modulo 2^16 like the reference's `short` stores.
 // ---------------------------------------------------------------------------------------------
-struct DcTriple { uint32_t y, cb, cr, f; };
-
-__global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_dc_local(PjdDevBatch B)
+__global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_lane_dc_local(PjdDevBatch B)
 {
     __shared__ uint32_t sy[PJD_DC_BLOCK], scb[PJD_DC_BLOCK], scr[PJD_DC_BLOCK], sf[PJD_DC_BLOCK];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t ii = B.dcblk_image[b];
-    const PjdDevImage &im = B.images[ii];
-    uint32_t *agg = B.dc_agg + (size_t)b * 4;
-    const bool exact = (im.flags & PJD_IF_SEQUENTIAL) || (B.status[ii] & PJD_STW_NEEDS_EXACT);
-    if (exact) {                       // slot 0 already holds absolute DC values
-        if (tid < 4) agg[tid] = 0;
-        return;
-    }
-    const uint32_t m = (b - im.dcblk_base) * PJD_DC_BLOCK + tid;
-    const bool live = m >= im.first_mcu && m < im.last_mcu;
-    const uint32_t RI = im.restart_interval, dus = im.dus_per_mcu, nl = im.n_luma, nc = im.ncomp;
-    int16_t *du0 = B.dcv + im.du_base + (uint64_t)m * dus;
-    uint32_t d[6] = {0, 0, 0, 0, 0, 0};     // fully unrolled below: stays in registers
+    const uint32_t q = b * PJD_DC_BLOCK + tid;
     uint32_t vy = 0, vcb = 0, vcr = 0, head = 0;
-    if (live) {
-#pragma unroll
-        for (uint32_t k = 0; k < 6; k++)
-            if (k < dus) {
-                const uint32_t dv = (uint32_t)(int32_t)du0[k];
-                d[k] = dv;
-                if (k < nl) vy += dv; else if (k == nl) vcb = dv; else vcr = dv;
-            }
-        head = (m == im.first_mcu) || (RI != 0 && m % RI == 0);
+    if (q < B.n_lanes) {
+        const PjdDevLaneInfo li = B.lane_info[q];
+        vy = li.dc_sum[0]; vcb = li.dc_sum[1]; vcr = li.dc_sum[2]; head = li.seg_first;
     }
     sy[tid] = vy; scb[tid] = vcb; scr[tid] = vcr; sf[tid] = head;
     __syncthreads();
@@ -136,52 +116,58 @@ __global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_dc_local(PjdDevBatch B)
         }
         __syncthreads();
     }
-    if (live) {
-        uint32_t py = 0, pcb = 0, pcr = 0;            // prediction entering this MCU
-        if (!head && tid > 0) { py = sy[tid] - vy; pcb = scb[tid] - vcb; pcr = scr[tid] - vcr; }
-#pragma unroll
-        for (uint32_t k = 0; k < 6; k++)
-            if (k < dus) {
-                uint32_t val;
-                if (k < nl) { py += d[k]; val = py; }
-                else if (k == nl) val = pcb + d[k];
-                else val = pcr + d[k];
-                du0[k] = (int16_t)val;
-            }
+    if (q < B.n_lanes) {
+        // predictors entering this lane: the inclusive result of the lane before it, zero at a segment head
+        PjdDevLaneDc d;
+        d.dc_in[0] = d.dc_in[1] = d.dc_in[2] = 0;
+        d.abs = (uint16_t)(head | (tid > 0 ? sf[tid - 1] : 0u));
+        if (!head && tid > 0) { d.dc_in[0] = (uint16_t)sy[tid - 1]; d.dc_in[1] = (uint16_t)scb[tid - 1]; d.dc_in[2] = (uint16_t)scr[tid - 1]; }
+        B.lane_dc[q] = d;
     }
-    if (tid == PJD_DC_BLOCK - 1) { agg[0] = sy[tid]; agg[1] = scb[tid]; agg[2] = scr[tid]; agg[3] = sf[tid]; }
+    if (tid == PJD_DC_BLOCK - 1) {
+        uint16_t *agg = B.dc_blk + (size_t)b * 8;
+        agg[0] = (uint16_t)sy[tid]; agg[1] = (uint16_t)scb[tid]; agg[2] = (uint16_t)scr[tid]; agg[3] = (uint16_t)sf[tid];
+    }
 }
 
-__device__ __forceinline__ DcTriple dc_combine(const DcTriple &a, const DcTriple &b)   // a then b
+// One workgroup: carry-in of every block = exclusive segmented scan of the block aggregates.
+__global__ __launch_bounds__(256) void pjd_k_lane_dc_carry(PjdDevBatch B)
 {
-    DcTriple r;
-    r.y = b.f ? b.y : a.y + b.y; r.cb = b.f ? b.cb : a.cb + b.cb; r.cr = b.f ? b.cr : a.cr + b.cr;
-    r.f = a.f | b.f;
-    return r;
-}
-
-__global__ __launch_bounds__(64) void pjd_k_dc_carry(PjdDevBatch B)
-{
-    const PjdDevImage &im = B.images[blockIdx.x];
-    const uint32_t lane = threadIdx.x, n = im.n_dcblk;
-    DcTriple carry = {0, 0, 0, 0};
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t j = base + lane;
-        DcTriple v = {0, 0, 0, 0};
-        if (j < n) { const uint32_t *a = B.dc_agg + (size_t)(im.dcblk_base + j) * 4; v.y = a[0]; v.cb = a[1]; v.cr = a[2]; v.f = a[3]; }
-        for (int off = 1; off < 64; off <<= 1) {
-            DcTriple o;
-            o.y = __shfl_up(v.y, off); o.cb = __shfl_up(v.cb, off); o.cr = __shfl_up(v.cr, off); o.f = __shfl_up(v.f, off);
-            if ((int)lane >= off) v = dc_combine(o, v);
+    __shared__ uint32_t sy[256], scb[256], scr[256], sf[256];
+    const uint32_t tid = threadIdx.x, n = B.n_dcblk;
+    uint32_t cy = 0, ccb = 0, ccr = 0;                       // predictors entering the current chunk of blocks
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t j = base + tid;
+        uint32_t vy = 0, vcb = 0, vcr = 0, vf = 0;
+        if (j < n) { const uint16_t *a = B.dc_blk + (size_t)j * 8; vy = a[0]; vcb = a[1]; vcr = a[2]; vf = a[3]; }
+        sy[tid] = vy; scb[tid] = vcb; scr[tid] = vcr; sf[tid] = vf;
+        __syncthreads();
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            uint32_t ay = 0, acb = 0, acr = 0, af = 0;
+            const bool take = tid >= off;
+            if (take) { ay = sy[tid - off]; acb = scb[tid - off]; acr = scr[tid - off]; af = sf[tid - off]; }
+            const uint32_t myf = sf[tid];
+            __syncthreads();
+            if (take) {
+                if (!myf) { sy[tid] += ay; scb[tid] += acb; scr[tid] += acr; }
+                sf[tid] = myf | af;
+            }
+            __syncthreads();
         }
-        DcTriple prev;                     // inclusive result of lane-1
-        prev.y = __shfl_up(v.y, 1); prev.cb = __shfl_up(v.cb, 1); prev.cr = __shfl_up(v.cr, 1); prev.f = __shfl_up(v.f, 1);
-        DcTriple in = (lane == 0) ? carry : dc_combine(carry, prev);
-        if (j < n) { uint32_t *c = B.dc_carry + (size_t)(im.dcblk_base + j) * 4; c[0] = in.y; c[1] = in.cb; c[2] = in.cr; c[3] = 0; }
-        DcTriple last;
-        last.y = __shfl(v.y, 63); last.cb = __shfl(v.cb, 63); last.cr = __shfl(v.cr, 63); last.f = __shfl(v.f, 63);
-        carry = dc_combine(carry, last);
-        carry.f = 0;
+        if (j < n) {
+            // exclusive: what the blocks before j leave behind
+            uint32_t iy = cy, icb = ccb, icr = ccr;
+            if (tid > 0) {
+                const bool h = sf[tid - 1] != 0;
+                iy = (h ? 0u : cy) + sy[tid - 1]; icb = (h ? 0u : ccb) + scb[tid - 1]; icr = (h ? 0u : ccr) + scr[tid - 1];
+            }
+            uint16_t *c = B.dc_blk + (size_t)j * 8 + 4;
+            c[0] = (uint16_t)iy; c[1] = (uint16_t)icb; c[2] = (uint16_t)icr; c[3] = 0;
+        }
+        const bool h = sf[255] != 0;
+        const uint32_t ny = (h ? 0u : cy) + sy[255], ncb = (h ? 0u : ccb) + scb[255], ncr = (h ? 0u : ccr) + scr[255];
+        __syncthreads();
+        cy = ny; ccb = ncb; ccr = ncr;
     }
 }
 
@@ -321,7 +307,7 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
 // ---------------------------------------------------------------------------------------------
 // Fused back end.  One workgroup = up to 96 data units = a run of consecutive MCUs of one image.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs, const uint64_t *__restrict__ dense_base)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint16_t qs[3][64];
@@ -340,7 +326,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
     // ---- load (16 B per lane, coalesced), DC fix-up, de-zigzag, dequantise, row pass ----------
     // lane (du, r) owns zigzag slots 8r..8r+7 on load; after the scatter to natural order a
     // second sweep does the row pass.
-    const int16_t *cbase = B.coef + (im.dense_base + (uint64_t)wg.first_mcu * dus) * 64;
+    const int16_t *cbase = B.coef + (dense_base[wg.pad_] + (uint64_t)(wg.first_mcu - im.first_mcu) * dus) * 64;
     for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) {
         const uint32_t du = i >> 3, r = i & 7;
         const uint32_t ml = du / dus, k = du - ml * dus;
@@ -379,125 +365,199 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sparse front end: the parallel entropy decoder leaves, per data unit, a run of 4-byte entries
-// (value << 16 | zigzag slot, AC only) delimited by du_end[] / seg_ent[], and the DC in dcv[].
+// Lane-stream front end: the parallel entropy decoder leaves one 16-bit entry per symbol in per-lane
+// regions (layout: pjd_internal.h) and, for the first data unit of every IDCT workgroup, a mark
+// (lane, entry offset, DC sums so far).  The workgroup walks the entries from its mark, 1024 at a time:
+// unit index = number of "unit complete" bits before an entry, zigzag slot = sum of (run + 1) over the
+// unit so far -- two scans over the chunk -- then de-zigzags and dequantises into the LDS tile.
 // ---------------------------------------------------------------------------------------------
-// The eight threads that own a data unit (one wave always holds all eight) take it from entries to
-// finished samples on their own: clear, scatter (de-zigzag + dequantise), row pass, column pass.  LDS
-// traffic of one wave is processed in program order, so wave-local fences are all these steps need;
-// the workgroup meets once, before the colour stage, which mixes units of different waves.
-#define PJD_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
-                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define PJD_PARSE_PER_THREAD 4
+#define PJD_PARSE_CHUNK (PJD_IDCT_THREADS * PJD_PARSE_PER_THREAD)
 
-__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_sparse(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs)
+struct ParseAgg { uint32_t nl, tail, has; };       // units completed, (run + 1) summed after the last of them, any completed
+__device__ __forceinline__ ParseAgg parse_combine(const ParseAgg &a, const ParseAgg &b)   // a then b
+{
+    ParseAgg r;
+    r.nl = a.nl + b.nl; r.tail = b.has ? b.tail : a.tail + b.tail; r.has = a.has | b.has;
+    return r;
+}
+
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdDevBatch B)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
     __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
+    __shared__ int dcraw[PJD_IDCT_MAX_DU];    // DC difference of every unit
+    __shared__ uint32_t s52[PJD_IDCT_MAX_DU]; // entry at slot 52, if the unit has one
+    __shared__ uint32_t wagg[2][4][4];        // per chunk parity, per wave: ParseAgg
 
-    const PjdDevIdctWg wg = wgs[blockIdx.x];
+    const PjdDevIdctWg wg = B.iwgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
     if ((im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT)) return;   // the dense path redoes it
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t dus = im.dus_per_mcu, nl = im.n_luma;
     const uint32_t n_du = wg.n_mcu * dus;
     const uint32_t RI = im.restart_interval;
-    const uint32_t d0 = wg.first_mcu * dus;                     // image-relative index of the first unit
 
     if (tid < 192) {
         const uint32_t nat = c_zz[tid & 63];
         qz[tid >> 6][tid & 63] = (uint32_t)B.qtab[(size_t)wg.image * 192 + (tid & ~63u) + nat] | (nat << 16);
     }
+    // unvisited positions are zero (the reference's buffers start zeroed)
+    for (uint32_t i = tid; i < n_du * (TILE_STRIDE * 2 / 16); i += PJD_IDCT_THREADS)
+        reinterpret_cast<uint4 *>(&tile[0][0])[i] = make_uint4(0, 0, 0, 0);
+    if (tid < PJD_IDCT_MAX_DU) { s52[tid] = 0; dcraw[tid] = 0; }
+
+    const PjdDevMark mark = B.marks[blockIdx.x];
+    const uint32_t lane_end = im.lane_base + im.n_lane;
+    uint32_t q = mark.lane, n = mark.ent_off;
+    if (q < im.lane_base || q >= lane_end) return;              // never on a verified image; keeps a stale mark harmless
+    // predictors at the first unit: lane start (block-relative or absolute) + block carry + sums inside the lane
+    uint32_t pred0[3];
+    {
+        const PjdDevLaneDc ld = B.lane_dc[q];
+        const uint16_t *carry = B.dc_blk + (size_t)(q / PJD_DC_BLOCK) * 8 + 4;
+#pragma unroll
+        for (int c = 0; c < 3; c++) pred0[c] = (uint32_t)ld.dc_in[c] + (ld.abs ? 0u : (uint32_t)carry[c]) + mark.acc[c];
+    }
     __syncthreads();
 
-    const uint32_t *ent = B.ent + im.ent_base;
-    const uint32_t *de = B.du_end + im.du_base;
-    const int16_t *dcv = B.dcv + im.du_base;
-    // A thread owns one eighth of up to NIT data units.  Everything it needs from HBM is requested before
-    // anything is used: bounds and DC of all its units, then the first entry of each (a unit rarely has more
-    // than eight entries), so a workgroup waits for two memory round trips, not six.
-    constexpr int NIT = PJD_IDCT_MAX_DU * 8 / PJD_IDCT_THREADS;
-    uint32_t lo[NIT], hi[NIT], comp[NIT], w0[NIT], s52[NIT];
-    int dc[NIT];
-    bool on[NIT];
-    const uint32_t r = tid & 7;
+    // ---- parse: entries -> tile
+    ParseAgg run_agg = {0, 0, 0};                               // over the chunks so far (uniform)
+    uint32_t n_ent = B.lane_info[q].n_ent;
+    for (uint32_t it = 0; run_agg.nl < n_du; ) {
+        if (n >= n_ent) {                                       // next lane of the image
+            q++; n = 0;
+            if (q >= lane_end) break;
+            n_ent = B.lane_info[q].n_ent;
+            continue;
+        }
+        const uint32_t cnt = n_ent - n < PJD_PARSE_CHUNK ? n_ent - n : PJD_PARSE_CHUNK;
+        const uint16_t *src = B.ent + (size_t)q * B.lane_cap + n;
+        const uint32_t i0 = tid * PJD_PARSE_PER_THREAD;
+        uint32_t e[PJD_PARSE_PER_THREAD], prev = 0;
+        {
+            struct __attribute__((packed, aligned(2))) E4 { uint32_t a, b; };
+            E4 raw = {0, 0};
+            if (i0 < cnt) raw = *reinterpret_cast<const E4 *>(src + i0);     // reads inside the lane's region (cap is a multiple of 4 past any n_ent)
+            e[0] = raw.a & 0xffffu; e[1] = raw.a >> 16; e[2] = raw.b & 0xffffu; e[3] = raw.b >> 16;
+            if (i0 > 0 && i0 < cnt) prev = src[i0 - 1];
+        }
+        // the entry before a thread's first one tells whether that one opens a unit; at the chunk start the running tail does
+        bool dc_next = i0 == 0 ? run_agg.tail == 0 : (prev & PJD_ENT_LAST) != 0;
+        bool isdc[PJD_PARSE_PER_THREAD];
+        uint32_t adv[PJD_PARSE_PER_THREAD], last[PJD_PARSE_PER_THREAD];
+        ParseAgg mine = {0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < NIT; k++) {
-        const uint32_t du = (tid >> 3) + k * (PJD_IDCT_THREADS / 8);
-        on[k] = du < n_du;
-        lo[k] = hi[k] = 0; comp[k] = 0; dc[k] = 0;
-        if (on[k]) {
-            const uint32_t d = d0 + du, m = d / dus, kk = d - m * dus;
-            comp[k] = kk < nl ? 0 : kk - nl + 1;
-            // this unit's entries: [lo, hi) of the image's stream (the eight threads read the same two words)
-            const bool seg_first = kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
-            lo[k] = seg_first ? B.seg_ent[im.seg_base + (RI ? m / RI - im.first_mcu / RI : 0)] : de[d - 1];
-            hi[k] = de[d];
-            if (r == 0) {
-                dc[k] = dcv[d];
-                const uint32_t blk = m / PJD_DC_BLOCK;
-                const uint32_t hm = RI ? (m / RI) * RI : 0;      // last restart point at or before m
-                if (hm < blk * PJD_DC_BLOCK)                      // none inside this scan block: carry applies
-                    dc[k] = (int)(int16_t)((uint32_t)dc[k] + B.dc_carry[(size_t)(im.dcblk_base + blk) * 4 + comp[k]]);
+        for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
+            const bool valid = i0 + k < cnt;
+            isdc[k] = dc_next;
+            last[k] = valid ? (e[k] >> 11) & 1u : 0u;
+            adv[k] = valid ? (isdc[k] ? 1u : (e[k] >> 12) + 1u) : 0u;
+            dc_next = last[k] != 0;
+            mine.nl += last[k];
+            mine.tail = last[k] ? 0u : mine.tail + adv[k];
+            mine.has |= last[k];
+        }
+        // inclusive scan over the wave, then over the four waves through LDS
+        ParseAgg inc = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            ParseAgg o;
+            o.nl = __shfl_up(inc.nl, off); o.tail = __shfl_up(inc.tail, off); o.has = __shfl_up(inc.has, off);
+            if ((int)lane >= off) inc = parse_combine(o, inc);
+        }
+        if (lane == 63) { wagg[it & 1][wv][0] = inc.nl; wagg[it & 1][wv][1] = inc.tail; wagg[it & 1][wv][2] = inc.has; }
+        ParseAgg exc;                                           // everything before this thread, inside the wave
+        exc.nl = __shfl_up(inc.nl, 1); exc.tail = __shfl_up(inc.tail, 1); exc.has = __shfl_up(inc.has, 1);
+        if (lane == 0) { exc.nl = 0; exc.tail = 0; exc.has = 0; }
+        __syncthreads();
+        ParseAgg before = run_agg, total = run_agg;             // before this wave / after the whole chunk
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            ParseAgg a;
+            a.nl = wagg[it & 1][k][0]; a.tail = wagg[it & 1][k][1]; a.has = wagg[it & 1][k][2];
+            if (k < wv) before = parse_combine(before, a);
+            total = parse_combine(total, a);
+        }
+        exc = parse_combine(before, exc);
+        // scatter: de-zigzag + dequantise (reference src/jpeg_scanner.cpp:517, src/decoder_dpu.c:169-172)
+        uint32_t u = exc.nl, zpos = exc.tail;
+#pragma unroll
+        for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
+            if (i0 + k < cnt && u < n_du) {
+                if (isdc[k]) dcraw[u] = (int)(((e[k] & 0x7ffu) | ((e[k] >> 1) & 0x800u)) << 20) >> 20;
+                else {
+                    const int val = (int)(e[k] << 21) >> 21;
+                    const uint32_t slot = zpos + (e[k] >> 12);
+                    const bool term = (e[k] & 0xf7ffu) == 0;                     // EOB: completes the unit, stores nothing
+                    if (!term && slot < 64) {
+                        const uint32_t kk = u % dus, comp = kk < nl ? 0 : kk - nl + 1;
+                        if (slot == 52) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
+                        else { const uint32_t qe = qz[comp][slot]; tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu); }
+                    }
+                }
             }
-            // unvisited positions are zero (the reference's buffers start zeroed): 144 bytes = 9 x 16
-            int16_t *t = tile[du];
-            *reinterpret_cast<uint4 *>(t + r * 8) = make_uint4(0, 0, 0, 0);
-            if (r == 0) *reinterpret_cast<uint4 *>(t + 64) = make_uint4(0, 0, 0, 0);
+            zpos = last[k] ? 0u : zpos + adv[k];
+            u += last[k];
+        }
+        run_agg = total;
+        n += cnt;
+        it++;                                                   // the other copy of wagg next time: one barrier per chunk is enough
+    }
+    __syncthreads();
+
+    // ---- DC prediction over the range (reference src/jpeg_scanner.cpp:485-486) and the slot-52 rule
+    if (wv == 0) {
+        const uint32_t d0 = wg.first_mcu * dus;
+        uint32_t cy = pred0[0], cc = (pred0[1] & 0xffffu) | (pred0[2] << 16);   // predictors entering the next group of 64 units
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        for (uint32_t base = 0; base < n_du; base += 64) {
+            const uint32_t u = base + lane;
+            const bool on = u < n_du;
+            const uint32_t d = d0 + u, m = d / dus, kk = d - m * dus, comp = kk < nl ? 0 : kk - nl + 1;
+            const uint32_t dv = on ? (uint32_t)dcraw[on ? u : 0] & 0xffffu : 0u;
+            uint32_t vy = comp == 0 ? dv : 0u, vc = comp == 1 ? dv : (comp == 2 ? dv << 16 : 0u);
+            uint32_t hf = (on && kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0))) ? 1u : 0u;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t oy = __shfl_up(vy, off), oc = __shfl_up(vc, off), of = __shfl_up(hf, off);
+                if ((int)lane >= off) {
+                    if (!hf) {
+                        vy += oy;
+                        vc = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, vc) + __builtin_bit_cast(u16x2, oc)));
+                    }
+                    hf |= of;
+                }
+            }
+            // inclusive sums since the last head (or since the group start): add what entered the group
+            uint32_t ty = vy, tc = vc;
+            if (!hf) { ty += cy; tc = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, tc) + __builtin_bit_cast(u16x2, cc))); }
+            if (on) {
+                const uint32_t dcv = comp == 0 ? ty : (comp == 1 ? tc : tc >> 16);
+                tile[u][0] = (int16_t)pjd_dequant((int)(int16_t)dcv, qz[comp][0] & 0xffffu);
+                if (s52[u]) tile[u][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[u] & 0xffffu), qz[comp][48] & 0xffffu);   // slot 48 -> natural 38
+            }
+            cy = __shfl(ty, 63); cc = __shfl(tc, 63);
         }
     }
-#pragma unroll
-    for (int k = 0; k < NIT; k++) w0[k] = (on[k] && lo[k] + r < hi[k]) ? ent[lo[k] + r] : 0xffffffffu;
-    PJD_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < NIT; k++) {
-        s52[k] = 0;                                              // entry at slot 52, if this thread met it
-        if (on[k]) {
-            const uint32_t du = (tid >> 3) + k * (PJD_IDCT_THREADS / 8);
-            const uint32_t *q = qz[comp[k]];
-            int16_t *t = tile[du];
-            if (r == 0) t[0] = (int16_t)pjd_dequant(dc[k], q[0] & 0xffffu);
-            uint32_t w = w0[k];
-            for (uint32_t e = lo[k] + r; e < hi[k]; ) {
-                const uint32_t slot = w & 63;
-                const int val = (int)(int16_t)(w >> 16);
-                if (slot == 52) s52[k] = 0x80000000u | (w >> 16);   // overrides slot 48 at natural 38, even when zero
-                else { const uint32_t e = q[slot]; t[e >> 16] = (int16_t)pjd_dequant(val, e & 0xffffu); }
-                e += 8;
-                if (e < hi[k]) w = ent[e];
-            }
-        }
-        s52[k] |= __shfl_xor(s52[k], 1); s52[k] |= __shfl_xor(s52[k], 2); s52[k] |= __shfl_xor(s52[k], 4);   // a unit visits slot 52 at most once
-    }
-    PJD_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < NIT; k++)
-        if (on[k] && s52[k] && r == 0)
-            tile[(tid >> 3) + k * (PJD_IDCT_THREADS / 8)][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[k] & 0xffffu), qz[comp[k]][48] & 0xffffu);   // slot 48 -> natural 38
-    PJD_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < NIT; k++) if (on[k]) pjd_tile_row(tile, (tid >> 3) + k * (PJD_IDCT_THREADS / 8), r);
-    PJD_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < NIT; k++) if (on[k]) pjd_tile_col(tile, (tid >> 3) + k * (PJD_IDCT_THREADS / 8), r);
-    pjd_tile_to_pixels<false>(tile, mcu_xy, B, im, wg, tid);
+    pjd_tile_to_pixels<true>(tile, mcu_xy, B, im, wg, tid);
 }
 
-void pjd_launch_idct_colour_sparse(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)
+void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b)
 {
-    if (n_wg == 0) return;
-    hipLaunchKernelGGL(pjd_k_idct_colour_sparse, dim3(n_wg), dim3(PJD_IDCT_THREADS), 0, s, b, wgs);
+    if (b.n_iwg == 0) return;
+    hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(b.n_iwg), dim3(PJD_IDCT_THREADS), 0, s, b);
 }
 
-void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg)
-{
-    if (n_wg == 0) return;
-    hipLaunchKernelGGL(pjd_k_idct_colour, dim3(n_wg), dim3(PJD_IDCT_THREADS), 0, s, b, wgs);
-}
-
-void pjd_launch_dc_scan(hipStream_t s, const PjdDevBatch &b)
+void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b)
 {
     if (b.n_dcblk == 0) return;
-    hipLaunchKernelGGL(pjd_k_dc_local, dim3(b.n_dcblk), dim3(PJD_DC_BLOCK), 0, s, b);
-    hipLaunchKernelGGL(pjd_k_dc_carry, dim3(b.n_images), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(pjd_k_lane_dc_local, dim3(b.n_dcblk), dim3(PJD_DC_BLOCK), 0, s, b);
+    hipLaunchKernelGGL(pjd_k_lane_dc_carry, dim3(1), dim3(256), 0, s, b);
 }
+
+void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, const uint64_t *dense_base, uint32_t n_wg)
+{
+    if (n_wg == 0) return;
+    hipLaunchKernelGGL(pjd_k_idct_colour, dim3(n_wg), dim3(PJD_IDCT_THREADS), 0, s, b, wgs, dense_base);
+}
+

@@ -12,7 +12,7 @@
 //   * images on which the parallel decoder met anything irregular (PJD_STW_NEEDS_EXACT).
 // It is slow by construction (one dependent chain per image) and is never the fast path.
 //
-// Output: coefficients in zigzag-SLOT order (slot k of data unit D at coef[(du_base+D)*64+k]),
+// Output: coefficients in zigzag-SLOT order (slot k of the D-th data unit decoded at coef[(dense_base+D)*64+k]),
 // absolute DC values in slot 0, and the PJD_COEF_SENTINEL mark for an explicit zero at slot 52.
 #include "pjd_device_common.h"
 #include "pjd_kernels.h"
@@ -68,67 +68,69 @@ __device__ int seq_bits(SeqReader &r, uint32_t n)
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void pjd_k_huff_sequential(PjdDevBatch B, const uint32_t *__restrict__ image_list)
+__global__ __launch_bounds__(64) void pjd_k_huff_sequential(PjdDevBatch B, const uint32_t *__restrict__ image_list, const uint64_t *__restrict__ dense_base)
 {
     if (threadIdx.x != 0) return;
     const uint32_t ii = image_list[blockIdx.x];
     const PjdDevImage &im = B.images[ii];
-    const PjdDevHuffRaw *tabs = B.raw_tables + (size_t)ii * PJD_MAX_TABLES;
+    const PjdDevHuffRaw *tabs = B.raw_tables + (size_t)im.tset * PJD_MAX_TABLES;
     SeqReader r = { B.ecs + im.ecs_off, im.ecs_len * 8u, 0u };
-    int16_t *coef = B.coef + im.dense_base * 64;
+    // slot 0 of the scratch = the first data unit this image (or this shard of it) decodes
+    int16_t *coef = B.coef + dense_base[blockIdx.x] * 64;
     const uint32_t RI = im.restart_interval, Wr = im.ref_mcu_w_real;
     const bool std_rule = (im.flags & PJD_IF_STANDARD_RESTART) != 0;
     int pred[3] = {0, 0, 0};
-    uint32_t D = 0, mcu_counter = 0;
+    uint32_t D = 0;
     int status = PJD_ST_OK;
 
-    for (uint32_t y = 0; y < im.ref_mcu_h && !status; y += im.vs)
-        for (uint32_t x = 0; x < im.ref_mcu_w && !status; x += im.hs) {
-            const bool restart = RI != 0 && (std_rule ? (mcu_counter % RI == 0) : ((y * Wr + x) % RI == 0));
-            if (restart) {
-                pred[0] = pred[1] = pred[2] = 0;
-                // BitReader::align(): no-op once every byte is consumed
-                if ((r.p >> 3) < im.ecs_len && (r.p & 7)) r.p = (r.p + 7) & ~7u;
-            }
-            mcu_counter++;
-            for (uint32_t k = 0; k < im.dus_per_mcu && !status; k++, D++) {
-                const uint32_t comp = k < im.n_luma ? 0 : k - im.n_luma + 1;
-                const PjdDevHuffRaw &dt = tabs[im.tbl_slot[comp][0]];
-                const PjdDevHuffRaw &at = tabs[im.tbl_slot[comp][1]];
-                int16_t *unit = coef + (size_t)D * 64;
-                // ---- DC (jpeg_scanner.cpp:469-486)
-                int s = seq_symbol(r, dt);
-                if (s < 0 || s == 0xFF) { status = PJD_ST_DC_SYM; break; }
-                if (s > 11) { status = PJD_ST_DC_LEN; break; }
-                int v = seq_bits(r, (uint32_t)s);
-                if (v == -1) { status = PJD_ST_DC_BITS; break; }
-                if (s != 0 && v < (1 << (s - 1))) v -= (1 << s) - 1;
-                unit[0] = (int16_t)(v + pred[comp]);
-                pred[comp] = unit[0];
-                // ---- AC (jpeg_scanner.cpp:488-518)
-                for (uint32_t z = 1; z < 64; z++) {
-                    int sym = seq_symbol(r, at);
-                    if (sym < 0 || sym == 0xFF) { status = PJD_ST_AC_SYM; break; }
-                    if (sym == 0) break;
-                    const uint32_t run = (uint32_t)sym >> 4, len = (uint32_t)sym & 15;
-                    if (z + run >= 64) { status = PJD_ST_AC_RUN; break; }
-                    z += run;
-                    if (len > 10) { status = PJD_ST_AC_LEN; break; }
-                    v = seq_bits(r, len);
-                    if (v == -1) { status = PJD_ST_AC_BITS; break; }
-                    if (len != 0 && v < (1 << (len - 1))) v -= (1 << len) - 1;
-                    // len == 0 stores a literal 0 (jpeg_scanner.cpp:516-517); it matters only at
-                    // slot 52, whose natural position (38) may already hold slot 48's value
-                    unit[z] = (len == 0 && z == 52) ? (int16_t)PJD_COEF_SENTINEL : (int16_t)v;
-                }
+    // reference loop `for y < mcu_height step V, for x < mcu_width step H` (jpeg_scanner.cpp:721-722) by MCU
+    // counter; a shard starts at a restart point, where the reference's state is (zero predictors, byte boundary)
+    for (uint32_t m = im.first_mcu; m < im.last_mcu && !status; m++) {
+        const uint32_t y = (m / im.mcux) * im.vs, x = (m % im.mcux) * im.hs;
+        const bool restart = RI != 0 && (std_rule ? (m % RI == 0) : ((y * Wr + x) % RI == 0));
+        if (restart) {
+            pred[0] = pred[1] = pred[2] = 0;
+            // BitReader::align(): no-op once every byte is consumed
+            if ((r.p >> 3) < im.ecs_len && (r.p & 7)) r.p = (r.p + 7) & ~7u;
+        }
+        for (uint32_t k = 0; k < im.dus_per_mcu && !status; k++, D++) {
+            const uint32_t comp = k < im.n_luma ? 0 : k - im.n_luma + 1;
+            const PjdDevHuffRaw &dt = tabs[im.tbl_slot[comp][0]];
+            const PjdDevHuffRaw &at = tabs[im.tbl_slot[comp][1]];
+            int16_t *unit = coef + (size_t)D * 64;
+            // ---- DC (jpeg_scanner.cpp:469-486)
+            int s = seq_symbol(r, dt);
+            if (s < 0 || s == 0xFF) { status = PJD_ST_DC_SYM; break; }
+            if (s > 11) { status = PJD_ST_DC_LEN; break; }
+            int v = seq_bits(r, (uint32_t)s);
+            if (v == -1) { status = PJD_ST_DC_BITS; break; }
+            if (s != 0 && v < (1 << (s - 1))) v -= (1 << s) - 1;
+            unit[0] = (int16_t)(v + pred[comp]);
+            pred[comp] = unit[0];
+            // ---- AC (jpeg_scanner.cpp:488-518)
+            for (uint32_t z = 1; z < 64; z++) {
+                int sym = seq_symbol(r, at);
+                if (sym < 0 || sym == 0xFF) { status = PJD_ST_AC_SYM; break; }
+                if (sym == 0) break;
+                const uint32_t run = (uint32_t)sym >> 4, len = (uint32_t)sym & 15;
+                if (z + run >= 64) { status = PJD_ST_AC_RUN; break; }
+                z += run;
+                if (len > 10) { status = PJD_ST_AC_LEN; break; }
+                v = seq_bits(r, len);
+                if (v == -1) { status = PJD_ST_AC_BITS; break; }
+                if (len != 0 && v < (1 << (len - 1))) v -= (1 << len) - 1;
+                // len == 0 stores a literal 0 (jpeg_scanner.cpp:516-517); it matters only at
+                // slot 52, whose natural position (38) may already hold slot 48's value
+                unit[z] = (len == 0 && z == 52) ? (int16_t)PJD_COEF_SENTINEL : (int16_t)v;
             }
         }
+    }
     // keep the "decoded by the exact kernel" marker so the back end treats slot 0 as absolute
     B.status[ii] = (B.status[ii] & PJD_STW_NEEDS_EXACT) | status;
 }
 
-void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, uint32_t n)
+void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(pjd_k_huff_sequential, dim3(n), dim3(64), 0, s, b, image_list);
+    hipLaunchKernelGGL(pjd_k_huff_sequential, dim3(n), dim3(64), 0, s, b, image_list, dense_base);
 }

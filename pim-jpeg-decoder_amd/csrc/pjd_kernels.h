@@ -8,42 +8,48 @@
 // All device pointers of one batch, as the kernels see them.
 struct PjdDevBatch {
     const PjdDevImage *images;
-    const PjdDevHuffRaw *raw_tables;     // n_images * PJD_MAX_TABLES
-    uint8_t *luts;                       // decode tables, one blob per image (PjdDevImage::lut_off16)
+    const PjdDevTset *tsets;
+    const PjdDevHuffRaw *raw_tables;     // n_tsets * PJD_MAX_TABLES
+    uint8_t *luts;                       // decode tables, one blob per table set (PjdDevTset::lut_off16)
     const uint16_t *qtab;                // n_images * 3 * 64
     const PjdDevSegment *segs;
-    const PjdDevSub *subs;
+    const PjdDevSub *lanes;
+    const PjdDevHuffWave *hwaves;
     const PjdDevHuffWg *hwgs;
     const PjdDevIdctWg *iwgs;
     const uint8_t *ecs;
+    uint32_t *words;                     // transposed bitstream words: [wave][PJD_WORD_ROWS][64]
     int16_t *coef;                       // DENSE scratch (exact-kernel path): dense_du * 64 int16, zigzag-slot order
-    uint32_t *ent;                       // coefficient entries of the parallel path: (value << 16) | slot, AC only
-    uint32_t *du_end;                    // per data unit: entry index (image-relative) just past its last entry
-    uint32_t *seg_ent;                   // per restart segment: entry index (image-relative) of its first entry
-    int16_t *dcv;                        // per data unit: DC difference, integrated in place by pjd_k_dc_*
+    uint16_t *ent;                       // lane streams: lane q owns entries [q * lane_cap, (q + 1) * lane_cap)
+    PjdDevLaneInfo *lane_info;           // per lane
+    PjdDevLaneDc *lane_dc;               // per lane
+    uint16_t *dc_blk;                    // per DC scan block: aggregate {Y, Cb, Cr, has_head}, then carry-in {Y, Cb, Cr, -}
+    PjdDevMark *marks;                   // per IDCT workgroup of the parallel path
     uint8_t *out;
     int32_t *status;                     // per image
-    // Huffman one-pass scratch (zeroed before every launch)
-    uint64_t *wg_exit;                   // [2][n_hwg]: exit state of a wave's last owned subsequence | flag; generation 0 / 1
-    uint64_t *wg_desc;                   // per Huffman workgroup: look-back descriptor (status | poison | head | units | entries)
-    uint32_t *ticket;                    // wave index dispenser
+    // Huffman kernel scratch (zeroed before every launch)
+    uint64_t *wave_gen;                  // [3][n_hwave]: exit state of a wave's last lane | flag; generations A / B / C
+    uint64_t *wave_desc;                 // per Huffman wave: look-back descriptor (status | poison | head | units)
+    uint32_t *ticket;                    // workgroup index dispenser
     uint32_t *dbg;                       // PJD_DEBUG_STATS: per wave, 8 timestamps (10 ns units); else null
-    // DC prediction scratch
-    uint32_t *dc_agg;                    // per DC block: {sumY, sumCb, sumCr, has_head}
-    uint32_t *dc_carry;                  // per DC block: carry-in {Y, Cb, Cr, pad}
-    const uint32_t *dcblk_image;         // per DC block: owning image
-    unsigned long long *stats;           // [16] diagnostics: 0 re-sync rounds (stage A), 1 lane passes in them, 2 / 3 the same for the stitch stage (B)
-    uint32_t n_images, n_hwg, n_iwg, n_dcblk;
+    unsigned long long *stats;           // [16] diagnostics: 0 re-sync rounds, 1 lane passes in them, 2 / 3 the same for the stitch
+                                         //      stage, PJD_STAT_FLAG0.. waves that flagged their image, by reason
+    uint32_t n_images, n_tsets, n_lanes, n_hwave, n_hwg, n_iwg, n_dcblk;
     uint32_t sub_bytes;                  // Huffman subsequence size of this batch
-    uint32_t max_lut_bytes;              // largest PjdDevImage::lut_bytes in the batch (sizes the dynamic LDS of the Huffman kernels)
+    uint32_t word_rows;                  // PJD_WORD_ROWS(sub_bytes)
+    uint32_t lane_cap;                   // PJD_LANE_CAP(sub_bytes)
+    uint32_t max_lut_bytes;              // largest PjdDevTset::lut_bytes in the batch (sizes the dynamic LDS of the Huffman kernel)
 };
 
 // ---- back end (pjd_k_backend.hip) ------------------------------------------------
 void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus);
-void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg);          // dense input (exact path)
-void pjd_launch_idct_colour_sparse(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, uint32_t n_wg);   // entry-stream input
-void pjd_launch_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernels: local scan + carry
-// ---- entropy decode (pjd_k_huffman.hip) -----------------------------------------
-void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, uint32_t n);
+// dense input (exact path): wgs[k].pad_ = index into dense_base[] (data unit 0 of that image's scratch)
+void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, const uint64_t *dense_base, uint32_t n_wg);
+void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b);                                     // lane-stream input
+void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernels: local scan + carry
+// ---- entropy decode (pjd_k_huffman.hip, pjd_k_huffman_seq.hip) ---------------------
+// exact kernel: image_list[k] decodes into the dense scratch from data unit dense_base[k]
+void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
-void pjd_launch_huff_onepass(hipStream_t s, const PjdDevBatch &b);   // synchronise + stitch + scan + write
+void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b);     // bitstream -> per-lane big-endian words, transposed per wave
+void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b);     // synchronise + stitch + scan + write

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 
 namespace {
 
@@ -43,7 +44,6 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.out_format = out_format;
     P.images.resize(n);
     P.host.resize(n);
-    P.tables.assign((size_t)n * PJD_MAX_TABLES, PjdDevHuffRaw());
     P.qtab.assign((size_t)n * 3 * 64, 0);
 
     // Subsequence size.  The self-synchronisation distance of a 4:2:0 stream is ~160 B on average
@@ -64,7 +64,9 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     }
     const uint32_t SB = P.sub_bytes;
 
-    uint64_t ecs_off = 0, out_off = 0, du_base = 0, dcblk = 0, ent_base = 0, dense_seq = 0, dense_fb = 0, lut_off = 0;
+    uint64_t ecs_off = 0, out_off = 0, du_total = 0, dense_seq = 0, lut_off = 0;
+    std::map<std::string, uint32_t> tset_of;       // raw bytes of a deduplicated table list -> table set
+    std::vector<char> tset_parallel;               // per set: the two-level tables fit the parallel decoder
     for (int i = 0; i < n; i++) {
         const pjd_image_desc &d = images[i];
         PjdDevImage &g = P.images[i];
@@ -109,56 +111,77 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         // ---- quantisation tables: the reference copies QT t only while every t' < t is set
         //      (decoder_host.cpp:173-178); later tables read as zero.  Only the low 16 bits of
         //      a product survive the int16 store (decoder_dpu.c:169-172).
-        for (int c = 0; c < g.ncomp; c++) {
+        for (int c = 0; c < (int)g.ncomp; c++) {
             bool visible = true;
             for (int t = 0; t <= d.comp_qt[c]; t++) visible = visible && d.qt_set[t];
             for (int k = 0; k < 64; k++)
                 P.qtab[((size_t)i * 3 + c) * 64 + k] = visible ? (uint16_t)d.qt[d.comp_qt[c]][k] : 0;
         }
 
-        // ---- Huffman tables: dedupe the (up to) 3 DC + 3 AC tables the components reference
+        // ---- Huffman tables: dedupe the (up to) 3 DC + 3 AC tables the components reference, then find or make
+        //      the table SET (identical lists share decode tables, and their waves can share a workgroup)
         int nt = 0;
         const pjd_huff_table *seen[PJD_MAX_TABLES];
-        for (int c = 0; c < g.ncomp; c++)
+        uint8_t seen_ac[PJD_MAX_TABLES];
+        for (int c = 0; c < (int)g.ncomp; c++)
             for (int a = 0; a < 2; a++) {
                 const pjd_huff_table *t = a ? &d.ac[d.comp_ac[c]] : &d.dc[d.comp_dc[c]];
-                int s = -1;
+                int sl = -1;
                 for (int k = 0; k < nt; k++)
-                    if (P.tables[(size_t)i * PJD_MAX_TABLES + k].is_ac == a && same_table(*seen[k], *t)) { s = k; break; }
-                if (s < 0) {
-                    s = nt++;
-                    seen[s] = t;
-                    PjdDevHuffRaw &r = P.tables[(size_t)i * PJD_MAX_TABLES + s];
-                    std::memcpy(r.offsets, t->offsets, 17);
-                    std::memcpy(r.symbols, t->symbols, 162);
-                    r.is_ac = (uint8_t)a;
-                }
-                g.tbl_slot[c][a] = (uint8_t)s;
+                    if (seen_ac[k] == a && same_table(*seen[k], *t)) { sl = k; break; }
+                if (sl < 0) { sl = nt++; seen[sl] = t; seen_ac[sl] = (uint8_t)a; }
+                g.tbl_slot[c][a] = (uint8_t)sl;
             }
-        g.n_tables = (uint8_t)nt;
-        // decode-table layout (pjd_internal.h): first-level tables, then one 64-entry second-level table per
-        // 10-bit prefix that holds codes longer than 10 bits.  Over-subscribed tables (not a prefix code) and
-        // tables whose long codes need more LDS than PJD_LUT_LDS_MAX go to the exact kernel.
-        bool tables_parallel_ok = true;
-        uint32_t lut_bytes = (uint32_t)nt * PJD_L1_BYTES;
+        std::string key;
+        key.reserve((size_t)nt * 180);
         for (int k = 0; k < nt; k++) {
-            const PjdDevHuffRaw &r = P.tables[(size_t)i * PJD_MAX_TABLES + k];
-            uint32_t code = 0, end10 = 0;
-            for (int len = 1; len <= 16; len++) {            // reference generate_codes (jpeg_scanner.cpp:438-448)
-                const uint32_t cnt = (uint32_t)r.offsets[len] - r.offsets[len - 1];
-                if (code + cnt > (1u << len)) tables_parallel_ok = false;
-                if (len == PJD_LUT_BITS) end10 = code + cnt;
-                code = (code + cnt) << 1;
-            }
-            const uint32_t end16 = code >> 1;
-            uint32_t p0 = end10 < 1024 ? end10 : 1024, p1 = (end16 + 63) >> 6;
-            if (p1 > 1024) p1 = 1024;
-            if (p1 < p0 || !tables_parallel_ok) p1 = p0;
-            g.l2_p0[k] = (uint16_t)p0; g.l2_p1[k] = (uint16_t)p1;
-            g.l2_off[k] = (uint16_t)(lut_bytes / 2);
-            lut_bytes += (p1 - p0) * 128;
-            if (lut_bytes > PJD_LUT_LDS_MAX) { tables_parallel_ok = false; lut_bytes = (uint32_t)nt * PJD_L1_BYTES; }
+            key.push_back((char)seen_ac[k]);
+            key.append(reinterpret_cast<const char *>(seen[k]->offsets), 17);
+            key.append(reinterpret_cast<const char *>(seen[k]->symbols), 162);
         }
+        auto found = tset_of.find(key);
+        if (found == tset_of.end()) {
+            const uint32_t ts = (uint32_t)P.tsets.size();
+            found = tset_of.emplace(std::move(key), ts).first;
+            PjdDevTset T;
+            std::memset(&T, 0, sizeof T);
+            T.n_tables = (uint32_t)nt;
+            P.tables.resize((size_t)(ts + 1) * PJD_MAX_TABLES, PjdDevHuffRaw());
+            // decode-table layout (pjd_internal.h): first-level tables, then one 64-entry second-level table per
+            // 10-bit prefix that holds codes longer than 10 bits.  Over-subscribed tables (not a prefix code) and
+            // tables whose long codes need more LDS than PJD_LUT_LDS_MAX go to the exact kernel.
+            bool ok = true;
+            uint32_t lut_bytes = (uint32_t)nt * PJD_L1_BYTES;
+            for (int k = 0; k < nt; k++) {
+                PjdDevHuffRaw &r = P.tables[(size_t)ts * PJD_MAX_TABLES + k];
+                std::memcpy(r.offsets, seen[k]->offsets, 17);
+                std::memcpy(r.symbols, seen[k]->symbols, 162);
+                r.is_ac = seen_ac[k];
+                uint32_t code = 0, end10 = 0;
+                for (int len = 1; len <= 16; len++) {            // reference generate_codes (jpeg_scanner.cpp:438-448)
+                    const uint32_t cnt = (uint32_t)r.offsets[len] - r.offsets[len - 1];
+                    if (code + cnt > (1u << len)) ok = false;
+                    if (len == PJD_LUT_BITS) end10 = code + cnt;
+                    code = (code + cnt) << 1;
+                }
+                const uint32_t end16 = code >> 1;
+                uint32_t p0 = end10 < 1024 ? end10 : 1024, p1 = (end16 + 63) >> 6;
+                if (p1 > 1024) p1 = 1024;
+                if (p1 < p0 || !ok) p1 = p0;
+                T.l2_p0[k] = (uint16_t)p0; T.l2_p1[k] = (uint16_t)p1;
+                T.l2_off[k] = (uint16_t)(lut_bytes / 2);
+                lut_bytes += (p1 - p0) * 128;
+                if (lut_bytes > PJD_LUT_LDS_MAX) ok = false;
+            }
+            T.lut_bytes = ok ? (uint32_t)align_up(lut_bytes, 16) : 0;
+            T.lut_off16 = (uint32_t)(lut_off / 16);
+            lut_off += T.lut_bytes;
+            if (T.lut_bytes > P.max_lut_bytes) P.max_lut_bytes = T.lut_bytes;
+            P.tsets.push_back(T);
+            tset_parallel.push_back(ok ? 1 : 0);
+        }
+        g.tset = found->second;
+        const bool tables_parallel_ok = tset_parallel[g.tset] != 0;
 
         // ---- restart segments and routing
         const uint32_t RI = d.restart_interval;
@@ -173,7 +196,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             if (!luma11 && !std_rule) sequential = true;
             if (!d.seg_offsets || d.n_segments != nseg_total) sequential = true;
         }
-        if (!sequential && d.seg_offsets) {
+        if (!sequential && d.seg_offsets && d.n_segments > 0) {
             if (d.seg_offsets[0] != 0) sequential = true;
             for (uint32_t k = 1; k < d.n_segments && !sequential; k++)
                 if (d.seg_offsets[k] < d.seg_offsets[k - 1] || d.seg_offsets[k] > d.ecs_len) sequential = true;
@@ -186,10 +209,6 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         }
         h.sequential = sequential;
         if (sequential) g.flags |= PJD_IF_SEQUENTIAL;
-        g.lut_bytes = sequential ? 0 : (uint32_t)align_up(lut_bytes, 16);
-        g.lut_off16 = (uint32_t)(lut_off / 16);
-        lut_off += g.lut_bytes;
-        if (g.lut_bytes > P.max_lut_bytes) P.max_lut_bytes = g.lut_bytes;
 
         uint64_t byte_lo = 0, byte_hi = d.ecs_len;
         if (RI != 0 && !sequential) {
@@ -203,70 +222,71 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         h.ecs_copy_len = byte_hi - byte_lo;
         g.ecs_len = (uint32_t)h.ecs_copy_len;
         g.ecs_off = ecs_off;
-        ecs_off = align_up(ecs_off + h.ecs_copy_len + 48, 16);   // >= 48 zero bytes after every stream (lane prefetch reads ahead)
+        ecs_off = align_up(ecs_off + h.ecs_copy_len + 48, 16);   // >= 48 zero bytes after every stream (a symbol may start on its last bit)
 
         g.seg_base = (uint32_t)P.segs.size();
-        g.sub_base = (uint32_t)P.subs.size();
-        g.hwg_base = (uint32_t)P.hwgs.size();
+        g.lane_base = (uint32_t)P.subs.size();
+        g.hwave_base = (uint32_t)P.hwaves.size();
         if (!sequential) {
             for (uint32_t k = seg_lo; k < seg_hi; k++) {
-                PjdDevSegment s;
+                PjdDevSegment sg;
                 uint64_t b0 = (RI != 0) ? d.seg_offsets[k] : 0;
                 uint64_t b1 = (RI != 0 && k + 1 < nseg_total) ? d.seg_offsets[k + 1] : d.ecs_len;
-                s.byte_start = (uint32_t)(b0 - byte_lo);
-                s.byte_end = (uint32_t)(b1 - byte_lo);
+                sg.byte_start = (uint32_t)(b0 - byte_lo);
+                sg.byte_end = (uint32_t)(b1 - byte_lo);
                 uint32_t m0 = (RI != 0) ? k * RI : 0;
                 uint32_t m1 = (RI != 0) ? ((k + 1) * RI < g.n_mcu ? (k + 1) * RI : g.n_mcu) : g.n_mcu;
-                s.first_du = m0 * g.dus_per_mcu;
-                s.n_du = (m1 - m0) * g.dus_per_mcu;
+                sg.first_du = m0 * g.dus_per_mcu;
+                sg.n_du = (m1 - m0) * g.dus_per_mcu;
                 const uint32_t seg_index = (uint32_t)P.segs.size();
-                P.segs.push_back(s);
-                uint32_t len = s.byte_end - s.byte_start;
+                P.segs.push_back(sg);
+                uint32_t len = sg.byte_end - sg.byte_start;
                 uint32_t nsub = len ? (len + SB - 1) / SB : 1;
                 for (uint32_t j = 0; j < nsub; j++) {
                     PjdDevSub q;
-                    q.byte_start = s.byte_start + j * SB;
+                    q.byte_start = sg.byte_start + j * SB;
                     q.seg = seg_index | (j == 0 ? 0x80000000u : 0u);
                     P.subs.push_back(q);
                 }
             }
             g.n_seg = (uint32_t)P.segs.size() - g.seg_base;
-            g.n_sub = (uint32_t)P.subs.size() - g.sub_base;
-            for (uint32_t s0 = 0; s0 < g.n_sub; s0 += PJD_HUFF_OWNED) {
-                PjdDevHuffWg w;
+            g.n_lane = (uint32_t)P.subs.size() - g.lane_base;
+            for (uint32_t s0 = 0; s0 < g.n_lane; s0 += PJD_HUFF_LANES) {
+                PjdDevHuffWave w;
                 w.image = (uint32_t)i;
-                w.first_sub = g.sub_base + s0;
-                w.n_sub = (g.n_sub - s0 < PJD_HUFF_OWNED) ? g.n_sub - s0 : PJD_HUFF_OWNED;
+                w.first_lane = g.lane_base + s0;
+                w.n_lanes = (g.n_lane - s0 < PJD_HUFF_LANES) ? g.n_lane - s0 : PJD_HUFF_LANES;
                 w.pad_ = 0;
-                P.hwgs.push_back(w);
+                // workgroups: consecutive waves that use the same table set, PJD_HUFF_WAVES at most
+                if (P.hwgs.empty() || P.hwgs.back().tset != g.tset || P.hwgs.back().n_waves == PJD_HUFF_WAVES) {
+                    PjdDevHuffWg wgp;
+                    wgp.first_wave = (uint32_t)P.hwaves.size(); wgp.n_waves = 0; wgp.tset = g.tset; wgp.pad_ = 0;
+                    P.hwgs.push_back(wgp);
+                }
+                P.hwgs.back().n_waves++;
+                P.hwaves.push_back(w);
             }
-            g.n_hwg = (uint32_t)P.hwgs.size() - g.hwg_base;
+            g.n_hwave = (uint32_t)P.hwaves.size() - g.hwave_base;
             P.fast_images.push_back((uint32_t)i);
         } else {
             P.seq_images.push_back((uint32_t)i);
         }
 
-        // ---- coefficient entries, per-unit arrays, DC scan blocks, IDCT workgroups, output
+        // ---- dense scratch (exact-kernel images), IDCT workgroups, output
         g.image_index = (uint32_t)i;
-        g.du_base = du_base;
-        du_base += g.n_du;
-        // an AC entry costs at least 2 bits of stream (1-bit code + 1 value bit): capacity bound
-        g.ent_base = ent_base;
-        if (!sequential) ent_base = align_up(ent_base + h.ecs_copy_len * 4 + g.n_du + 8, 4);   // >= 2 bits per entry, +1 size-0 entry per unit
+        du_total += g.n_du;
         if (sequential) { g.dense_base = dense_seq; dense_seq += g.n_du; }
-        else if (g.n_du > dense_fb) dense_fb = g.n_du;
-        g.dcblk_base = (uint32_t)dcblk;
-        g.n_dcblk = (g.n_mcu + PJD_DC_BLOCK - 1) / PJD_DC_BLOCK;
-        dcblk += g.n_dcblk;
-        const uint32_t per_wg = PJD_IDCT_MAX_DU / g.dus_per_mcu;
-        for (uint32_t m = g.first_mcu; m < g.last_mcu; m += per_wg) {
+        g.idct_mcus = PJD_IDCT_MAX_DU / g.dus_per_mcu;
+        g.iwg_base = (uint32_t)(sequential ? P.iwgs_dense.size() : P.iwgs.size());
+        for (uint32_t m = g.first_mcu; m < g.last_mcu; m += g.idct_mcus) {
             PjdDevIdctWg w;
             w.image = (uint32_t)i;
             w.first_mcu = m;
-            w.n_mcu = (g.last_mcu - m < per_wg) ? g.last_mcu - m : per_wg;
-            w.pad_ = 0;
+            w.n_mcu = (g.last_mcu - m < g.idct_mcus) ? g.last_mcu - m : g.idct_mcus;
+            w.pad_ = sequential ? (uint32_t)(P.seq_images.size() - 1) : 0;   // dense path: which entry of the scratch-base list
             (sequential ? P.iwgs_dense : P.iwgs).push_back(w);
         }
+        g.n_iwg = (uint32_t)(sequential ? P.iwgs_dense.size() : P.iwgs.size()) - g.iwg_base;
         h.out_bytes = pjd_output_size(d.width, d.height, out_format);
         g.out_off = out_off;
         out_off = align_up(out_off + h.out_bytes, 256);
@@ -275,14 +295,16 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         P.ecs_bytes += d.ecs_len;
         P.out_bytes += h.out_bytes;
     }
-    P.ecs_buf_bytes = align_up(ecs_off + 256, 256);
-    P.n_du = du_base;
-    P.n_ent = ent_base + 16;
-    for (int i = 0; i < n; i++) if (!P.host[i].sequential) P.images[i].dense_base = dense_seq;   // shared fallback scratch
-    P.dense_du = dense_seq + dense_fb;
+    // the lane-word kernel copies PJD_WORD_ROWS words from every lane's first byte, whatever the lane's length
+    P.ecs_buf_bytes = align_up(ecs_off + PJD_SUB_BYTES_MAX + 64, 256);
+    P.n_du = du_total;
+    P.n_ent = (uint64_t)P.subs.size() * PJD_LANE_CAP(SB) + 16;
+    P.n_words = (uint64_t)P.hwaves.size() * PJD_WORD_ROWS(SB) * 64;
+    P.dense_du = dense_seq;
     P.out_buf_bytes = align_up(out_off, 256);
-    P.n_dcblk = dcblk;
+    P.n_dcblk = (P.subs.size() + PJD_DC_BLOCK - 1) / PJD_DC_BLOCK;
     P.lut_buf_bytes = align_up(lut_off + 16, 256);
     if (P.ecs_buf_bytes >= (1ull << 40)) { err = "batch bitstream too large"; return PJD_E_ARG; }
+    if (P.subs.size() >= (1ull << 31) || P.n_ent >= (1ull << 40)) { err = "batch has too many Huffman lanes"; return PJD_E_ARG; }
     return PJD_OK;
 }

@@ -18,23 +18,26 @@ struct PjdPlan {
     uint32_t sub_bytes = 512;              // Huffman subsequence size chosen for this batch
     std::vector<PjdDevImage> images;
     std::vector<PjdHostImage> host;
-    std::vector<PjdDevHuffRaw> tables;     // n_images * PJD_MAX_TABLES
+    std::vector<PjdDevTset> tsets;         // table sets: images with identical Huffman tables share one
+    std::vector<PjdDevHuffRaw> tables;     // n_tsets * PJD_MAX_TABLES
     std::vector<uint16_t> qtab;            // n_images * 3 * 64, natural order, low 16 bits
     std::vector<PjdDevSegment> segs;
-    std::vector<PjdDevSub> subs;
-    std::vector<PjdDevHuffWg> hwgs;
-    std::vector<PjdDevIdctWg> iwgs;        // images decoded by the parallel path (sparse back end)
+    std::vector<PjdDevSub> subs;           // Huffman lanes
+    std::vector<PjdDevHuffWave> hwaves;    // 64 consecutive lanes of one image
+    std::vector<PjdDevHuffWg> hwgs;        // up to 4 consecutive waves of one table set
+    std::vector<PjdDevIdctWg> iwgs;        // images decoded by the parallel path (lane-stream back end)
     std::vector<PjdDevIdctWg> iwgs_dense;  // images routed to the exact kernel up front (dense back end)
     std::vector<uint32_t> seq_images;      // indices of `sequential` images
     std::vector<uint32_t> fast_images;     // the others
     uint64_t ecs_buf_bytes = 0;            // size of the packed bitstream buffer (incl. padding)
     uint64_t n_du = 0;                     // data units in the batch
-    uint64_t n_ent = 0;                    // capacity of the coefficient-entry stream (entries)
+    uint64_t n_ent = 0;                    // capacity of the lane streams (16-bit entries): lanes * PJD_LANE_CAP
+    uint64_t n_words = 0;                  // transposed bitstream words: waves * PJD_WORD_ROWS * 64
     uint64_t dense_du = 0;                 // data units of the dense scratch (exact-kernel images + one fallback image)
     uint64_t out_buf_bytes = 0;
     uint64_t n_dcblk = 0;
-    uint64_t lut_buf_bytes = 0;            // decode-table blobs of all parallel-path images
-    uint32_t max_lut_bytes = 0;            // largest blob (dynamic LDS of the Huffman kernels)
+    uint64_t lut_buf_bytes = 0;            // decode-table blobs of all table sets the parallel path uses
+    uint32_t max_lut_bytes = 0;            // largest blob (dynamic LDS of the Huffman kernel)
     uint64_t pixels = 0, ecs_bytes = 0, out_bytes = 0;
 };
 

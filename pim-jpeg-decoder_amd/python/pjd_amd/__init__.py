@@ -55,7 +55,9 @@ class BatchInfo(C.Structure):
                 ("n_subsequences", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("n_sequential", C.c_int32), ("n_fallback", C.c_int32),
                 ("n_huff_workgroups", C.c_uint64), ("sync_rounds", C.c_uint64), ("sync_lane_passes", C.c_uint64),
-                ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64)]
+                ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64),
+                ("sub_bytes", C.c_uint32), ("n_table_sets", C.c_uint32), ("n_huff_waves", C.c_uint64),
+                ("n_entries", C.c_uint64), ("flag_waves", C.c_uint64 * 8)]
 
 
 class PjdError(RuntimeError):
@@ -289,7 +291,7 @@ class Batch:
     def info(self):
         bi = BatchInfo()
         self.ctx._check(self.L.pjd_batch_get_info(self._h, C.byref(bi)), "pjd_batch_get_info")
-        return {k: int(getattr(bi, k)) for k, _ in bi._fields_}
+        return {k: (list(getattr(bi, k)) if k == "flag_waves" else int(getattr(bi, k))) for k, _ in bi._fields_}
 
     def output_size(self, i):
         return int(self.L.pjd_batch_output_size(self._h, i))
@@ -415,4 +417,4 @@ def plan_info(descs, out_format=OUT_RGB8):
     rc = L.pjd_plan_info(arr, len(descs), out_format, C.byref(bi))
     if rc != 0:
         raise PjdError(f"pjd_plan_info failed ({rc})")
-    return {k: int(getattr(bi, k)) for k, _ in bi._fields_}
+    return {k: (list(getattr(bi, k)) if k == "flag_waves" else int(getattr(bi, k))) for k, _ in bi._fields_}
