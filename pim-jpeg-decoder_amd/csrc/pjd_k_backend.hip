@@ -305,6 +305,126 @@ __device__ __forceinline__ void pjd_tile_to_pixels(int16_t (*tile)[TILE_STRIDE],
 }
 
 // ---------------------------------------------------------------------------------------------
+// Chroma upsample + colour + raster store, specialised by sampling mode and output format (the generic version is
+// the tail of pjd_tile_to_pixels).  A thread takes a block of 4 x VS pixels: the VS picture rows share their chroma
+// samples (nearest neighbour, reference src/decoder_dpu.c:370), so the chroma terms of the conversion
+// (reference src/decoder_dpu.c:376-382) are computed once per sample.  A wave sweeps one row group across all MCUs of
+// the workgroup: its stores cover whole runs of a picture row.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed)) PjdPx12 { uint32_t a, b, c; };
+
+template <int HS, int VS, bool BMP>
+__device__ __forceinline__ void pjd_colour_store(const int16_t (*tile)[TILE_STRIDE], const uint32_t *mcu_xy, uint8_t *out,
+                                                 uint32_t width, uint32_t height, uint32_t stride, uint32_t ncomp,
+                                                 uint32_t n_mcu, uint32_t tid)
+{
+    constexpr uint32_t MW = 8 * HS, MH = 8 * VS, NL = HS * VS;
+    constexpr uint32_t CG_LOG = HS == 2 ? 2 : 1;               // log2 of the 4-pixel column groups per MCU row
+    constexpr int NCH = 4 / HS;                                 // chroma samples under 4 pixels
+    const uint32_t dus = NL + ncomp - 1;
+    const uint32_t per_row = n_mcu << CG_LOG;
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    for (uint32_t rg = wv; rg < 8; rg += PJD_IDCT_THREADS / 64) {          // row group = VS picture rows = one chroma row
+        for (uint32_t idx = lane; idx < per_row; idx += 64) {
+            const uint32_t ml = idx >> CG_LOG, px0 = (idx & ((1u << CG_LOG) - 1)) * 4;
+            const uint32_t xy = mcu_xy[ml];
+            const uint32_t X = __umul24(xy & 0xffffu, MW) + px0, Y0 = __umul24(xy >> 16, MH) + rg * VS;
+            if (X >= width || Y0 >= height) continue;
+            const uint32_t d0 = __umul24(ml, dus);
+            // chroma terms, ordered first / middle / last output byte (R,G,B -- or B,G,R for the BMP image), +128 included
+            int cf[NCH], cg[NCH], cl[NCH];
+            {
+                const uint32_t q = rg * 8 + px0 / HS;
+                uint32_t cbw[2] = {0, 0}, crw[2] = {0, 0};
+                if (ncomp > 1) {
+                    if (HS == 2) cbw[0] = *reinterpret_cast<const uint32_t *>(&tile[d0 + NL][q]);
+                    else { const uint2 t = *reinterpret_cast<const uint2 *>(&tile[d0 + NL][q]); cbw[0] = t.x; cbw[1] = t.y; }
+                }
+                if (ncomp > 2) {
+                    if (HS == 2) crw[0] = *reinterpret_cast<const uint32_t *>(&tile[d0 + NL + 1][q]);
+                    else { const uint2 t = *reinterpret_cast<const uint2 *>(&tile[d0 + NL + 1][q]); crw[0] = t.x; crw[1] = t.y; }
+                }
+#pragma unroll
+                for (int j = 0; j < NCH; j++) {
+                    const uint32_t bw = cbw[j >> 1], rw = crw[j >> 1];
+                    const int cbv = (j & 1) ? (int)bw >> 16 : (int)(int16_t)(bw & 0xffff);
+                    const int crv = (j & 1) ? (int)rw >> 16 : (int)(int16_t)(rw & 0xffff);
+                    const int rC = (__mul24(5880414, crv) >> 22) + 128, bC = (__mul24(7432306, cbv) >> 22) + 128;
+                    cg[j] = 128 - (__mul24(1442840, cbv) >> 22) - (__mul24(2994733, crv) >> 22);
+                    cf[j] = BMP ? bC : rC;
+                    cl[j] = BMP ? rC : bC;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VS; v++) {
+                const uint32_t Y = Y0 + v;
+                if (Y >= height) break;
+                const uint32_t py = rg * VS + v;
+                const int16_t *yp = &tile[d0 + (py >> 3) * HS + (px0 >> 3)][(py & 7) * 8 + (px0 & 7)];
+                const uint2 yraw = *reinterpret_cast<const uint2 *>(yp);               // 4 luma samples
+                const int y0 = (int16_t)(yraw.x & 0xffff), y1 = (int)yraw.x >> 16, y2 = (int16_t)(yraw.y & 0xffff), y3 = (int)yraw.y >> 16;
+                constexpr int s1 = HS == 2 ? 0 : 1, s2 = HS == 2 ? 1 : 2, s3 = HS == 2 ? 1 : 3;   // chroma sample of pixels 1..3
+                const uint32_t f0 = pjd_clamp255(y0 + cf[0]), g0 = pjd_clamp255(y0 + cg[0]), l0 = pjd_clamp255(y0 + cl[0]);
+                const uint32_t f1 = pjd_clamp255(y1 + cf[s1]), g1 = pjd_clamp255(y1 + cg[s1]), l1 = pjd_clamp255(y1 + cl[s1]);
+                const uint32_t f2 = pjd_clamp255(y2 + cf[s2]), g2 = pjd_clamp255(y2 + cg[s2]), l2 = pjd_clamp255(y2 + cl[s2]);
+                const uint32_t f3 = pjd_clamp255(y3 + cf[s3]), g3 = pjd_clamp255(y3 + cg[s3]), l3 = pjd_clamp255(y3 + cl[s3]);
+                uint8_t *o = BMP ? out + 26 + (size_t)(height - 1 - Y) * stride + X * 3 : out + (size_t)Y * stride + X * 3;
+                if (X + 4 <= width) {
+                    PjdPx12 px;
+                    px.a = f0 | (g0 << 8) | (l0 << 16) | (f1 << 24);
+                    px.b = g1 | (l1 << 8) | (f2 << 16) | (g2 << 24);
+                    px.c = l2 | (f3 << 8) | (g3 << 16) | (l3 << 24);
+                    *reinterpret_cast<PjdPx12 *>(o) = px;
+                } else {                                                             // right picture edge
+                    o[0] = (uint8_t)f0; o[1] = (uint8_t)g0; o[2] = (uint8_t)l0;
+                    if (X + 1 < width) { o[3] = (uint8_t)f1; o[4] = (uint8_t)g1; o[5] = (uint8_t)l1; }
+                    if (X + 2 < width) { o[6] = (uint8_t)f2; o[7] = (uint8_t)g2; o[8] = (uint8_t)l2; }
+                }
+            }
+        }
+    }
+}
+
+// BMP file header exactly as reference src/bmp_writer.cpp:32-41
+__device__ __forceinline__ void pjd_bmp_header(uint8_t *out, uint32_t width, uint32_t height, uint32_t stride, uint32_t tid)
+{
+    if (tid >= 26) return;
+    const uint32_t size = 26 + height * stride;
+    uint8_t hb = 0;
+    switch (tid) {
+        case 0: hb = 'B'; break;  case 1: hb = 'M'; break;
+        case 2: hb = size & 255; break; case 3: hb = (size >> 8) & 255; break;
+        case 4: hb = (size >> 16) & 255; break; case 5: hb = (size >> 24) & 255; break;
+        case 10: hb = 0x1A; break; case 14: hb = 12; break;
+        case 18: hb = width & 255; break; case 19: hb = (width >> 8) & 255; break;
+        case 20: hb = height & 255; break; case 21: hb = (height >> 8) & 255; break;
+        case 22: hb = 1; break; case 24: hb = 24; break;
+        default: hb = 0;
+    }
+    out[tid] = hb;
+}
+
+__device__ __forceinline__ void pjd_colour_dispatch(const int16_t (*tile)[TILE_STRIDE], const uint32_t *mcu_xy, const PjdDevBatch &B,
+                                                    const PjdDevImage &im, const PjdDevIdctWg &wg, uint32_t tid)
+{
+    uint8_t *out = B.out + im.out_off;
+    const uint32_t width = im.width, height = im.height, stride = im.out_stride, nc = im.ncomp, n = wg.n_mcu;
+    const bool bmp = (im.flags & PJD_IF_BMP) != 0;
+    if (bmp && wg.first_mcu == 0) pjd_bmp_header(out, width, height, stride, tid);
+    const uint32_t mode = (im.hs - 1) | ((im.vs - 1) << 1) | (bmp ? 4u : 0u);
+    switch (mode) {
+        case 0: pjd_colour_store<1, 1, false>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        case 1: pjd_colour_store<2, 1, false>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        case 2: pjd_colour_store<1, 2, false>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        case 3: pjd_colour_store<2, 2, false>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        case 4: pjd_colour_store<1, 1, true>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        case 5: pjd_colour_store<2, 1, true>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        case 6: pjd_colour_store<1, 2, true>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+        default: pjd_colour_store<2, 2, true>(tile, mcu_xy, out, width, height, stride, nc, n, tid); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused back end.  One workgroup = up to 96 data units = a run of consecutive MCUs of one image.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatch B, const PjdDevIdctWg *__restrict__ wgs, const uint64_t *__restrict__ dense_base)
@@ -374,11 +494,31 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 #define PJD_PARSE_PER_THREAD 4
 #define PJD_PARSE_CHUNK (PJD_IDCT_THREADS * PJD_PARSE_PER_THREAD)
 
-struct ParseAgg { uint32_t nl, tail, has; };       // units completed, (run + 1) summed after the last of them, any completed
-__device__ __forceinline__ ParseAgg parse_combine(const ParseAgg &a, const ParseAgg &b)   // a then b
+// Inclusive scans over the 64 lanes of a wave with DPP moves (VALU only, no LDS round trips): shifts inside each row of
+// 16 lanes, then the last lane of a row broadcast into the following rows.  Values are unsigned; 0 is the identity of both.
+#define PJD_DPP_STEP(OP, v, ctrl, rmask)                                                               \
+    do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, false); v = OP(v, t_); } while (0)
+__device__ __forceinline__ uint32_t pjd_op_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t pjd_op_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t pjd_op_pkadd(uint32_t a, uint32_t b)
 {
-    ParseAgg r;
-    r.nl = a.nl + b.nl; r.tail = b.has ? b.tail : a.tail + b.tail; r.has = a.has | b.has;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pjd_op_pksub(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
+}
+#define PJD_WAVE_SCAN(OP, v)                                                                           \
+    do {                                                                                                \
+        PJD_DPP_STEP(OP, v, 0x111, 0xf); PJD_DPP_STEP(OP, v, 0x112, 0xf); PJD_DPP_STEP(OP, v, 0x114, 0xf);  \
+        PJD_DPP_STEP(OP, v, 0x118, 0xf); PJD_DPP_STEP(OP, v, 0x142, 0xa); PJD_DPP_STEP(OP, v, 0x143, 0xc);  \
+    } while (0)
+// the inclusive value of the lane before (0 in lane 0)
+__device__ __forceinline__ uint32_t pjd_wave_prev(uint32_t v)
+{
+    const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     return r;
 }
 
@@ -389,7 +529,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
     __shared__ int dcraw[PJD_IDCT_MAX_DU];    // DC difference of every unit
     __shared__ uint32_t s52[PJD_IDCT_MAX_DU]; // entry at slot 52, if the unit has one
-    __shared__ uint32_t wagg[2][4][4];        // per chunk parity, per wave: ParseAgg
+    __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
+    __shared__ uint32_t wagg[2][4][2];        // per chunk parity, per wave: (units completed << 16 | sum of run+1), max unit-start mark
 
     const PjdDevIdctWg wg = B.iwgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
@@ -406,7 +547,11 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     // unvisited positions are zero (the reference's buffers start zeroed)
     for (uint32_t i = tid; i < n_du * (TILE_STRIDE * 2 / 16); i += PJD_IDCT_THREADS)
         reinterpret_cast<uint4 *>(&tile[0][0])[i] = make_uint4(0, 0, 0, 0);
-    if (tid < PJD_IDCT_MAX_DU) { s52[tid] = 0; dcraw[tid] = 0; }
+    if (tid < PJD_IDCT_MAX_DU) {
+        s52[tid] = 0; dcraw[tid] = 0;
+        const uint32_t kk = tid % dus;                          // the range starts on an MCU boundary
+        comp_of[tid] = (uint8_t)(kk < nl ? 0 : kk - nl + 1);
+    }
 
     const PjdDevMark mark = B.marks[blockIdx.x];
     const uint32_t lane_end = im.lane_base + im.n_lane;
@@ -420,12 +565,14 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 #pragma unroll
         for (int c = 0; c < 3; c++) pred0[c] = (uint32_t)ld.dc_in[c] + (ld.abs ? 0u : (uint32_t)carry[c]) + mark.acc[c];
     }
+    uint32_t n_ent = B.lane_info[q].n_ent;
     __syncthreads();
 
-    // ---- parse: entries -> tile
-    ParseAgg run_agg = {0, 0, 0};                               // over the chunks so far (uniform)
-    uint32_t n_ent = B.lane_info[q].n_ent;
-    for (uint32_t it = 0; run_agg.nl < n_du; ) {
+    // ---- parse: entries -> tile.  Per entry: U = units completed before it, A = (run + 1) summed over the entries
+    // before it (a DC entry counts 1), M = A at the start of its unit; zigzag slot = A - M + run.  U and A come from one
+    // additive scan, M from a max scan (A never decreases).
+    uint32_t run_units = 0, run_tail = 0;                       // over the chunks so far (uniform): units done, A - M at the chunk start
+    for (uint32_t it = 0; run_units < n_du; ) {
         if (n >= n_ent) {                                       // next lane of the image
             q++; n = 0;
             if (q >= lane_end) break;
@@ -444,10 +591,10 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             if (i0 > 0 && i0 < cnt) prev = src[i0 - 1];
         }
         // the entry before a thread's first one tells whether that one opens a unit; at the chunk start the running tail does
-        bool dc_next = i0 == 0 ? run_agg.tail == 0 : (prev & PJD_ENT_LAST) != 0;
+        bool dc_next = i0 == 0 ? run_tail == 0 : (prev & PJD_ENT_LAST) != 0;
         bool isdc[PJD_PARSE_PER_THREAD];
         uint32_t adv[PJD_PARSE_PER_THREAD], last[PJD_PARSE_PER_THREAD];
-        ParseAgg mine = {0, 0, 0};
+        uint32_t sum = 0;                                       // units << 16 | adv, over this thread's entries
 #pragma unroll
         for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
             const bool valid = i0 + k < cnt;
@@ -455,54 +602,70 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             last[k] = valid ? (e[k] >> 11) & 1u : 0u;
             adv[k] = valid ? (isdc[k] ? 1u : (e[k] >> 12) + 1u) : 0u;
             dc_next = last[k] != 0;
-            mine.nl += last[k];
-            mine.tail = last[k] ? 0u : mine.tail + adv[k];
-            mine.has |= last[k];
+            sum += adv[k] + (last[k] << 16);
         }
-        // inclusive scan over the wave, then over the four waves through LDS
-        ParseAgg inc = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-            ParseAgg o;
-            o.nl = __shfl_up(inc.nl, off); o.tail = __shfl_up(inc.tail, off); o.has = __shfl_up(inc.has, off);
-            if ((int)lane >= off) inc = parse_combine(o, inc);
-        }
-        if (lane == 63) { wagg[it & 1][wv][0] = inc.nl; wagg[it & 1][wv][1] = inc.tail; wagg[it & 1][wv][2] = inc.has; }
-        ParseAgg exc;                                           // everything before this thread, inside the wave
-        exc.nl = __shfl_up(inc.nl, 1); exc.tail = __shfl_up(inc.tail, 1); exc.has = __shfl_up(inc.has, 1);
-        if (lane == 0) { exc.nl = 0; exc.tail = 0; exc.has = 0; }
+        uint32_t inc = sum;
+        PJD_WAVE_SCAN(pjd_op_add, inc);
+        if (lane == 63) wagg[it & 1][wv][0] = inc;
+        uint32_t exc = pjd_wave_prev(inc);                      // everything before this thread, inside the wave
         __syncthreads();
-        ParseAgg before = run_agg, total = run_agg;             // before this wave / after the whole chunk
+        uint32_t before = run_tail, total = run_tail;           // adds of the waves before this one / of the whole chunk
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
-            ParseAgg a;
-            a.nl = wagg[it & 1][k][0]; a.tail = wagg[it & 1][k][1]; a.has = wagg[it & 1][k][2];
-            if (k < wv) before = parse_combine(before, a);
-            total = parse_combine(total, a);
+            const uint32_t a = wagg[it & 1][k][0];
+            if (k < wv) before += a;
+            total += a;
         }
-        exc = parse_combine(before, exc);
+        exc += before;                                          // units completed in this chunk before the thread << 16 | A
+        // unit-start marks: A just after every completed unit, max-scanned
+        uint32_t mloc = 0, a_run = exc & 0xffffu, mk[PJD_PARSE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
+            mk[k] = mloc;                                       // mark from this thread's own earlier entries (0: none)
+            a_run += adv[k];
+            if (last[k]) mloc = a_run;
+        }
+        uint32_t minc = mloc;
+        PJD_WAVE_SCAN(pjd_op_max, minc);
+        if (lane == 63) wagg[it & 1][wv][1] = minc;
+        uint32_t mexc = pjd_wave_prev(minc);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t a = wagg[it & 1][k][1];
+            if (k < wv) mexc = pjd_op_max(mexc, a);
+        }
         // scatter: de-zigzag + dequantise (reference src/jpeg_scanner.cpp:517, src/decoder_dpu.c:169-172)
-        uint32_t u = exc.nl, zpos = exc.tail;
+        uint32_t u = run_units + (exc >> 16), a_pos = exc & 0xffffu;
 #pragma unroll
         for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
             if (i0 + k < cnt && u < n_du) {
                 if (isdc[k]) dcraw[u] = (int)(((e[k] & 0x7ffu) | ((e[k] >> 1) & 0x800u)) << 20) >> 20;
                 else {
                     const int val = (int)(e[k] << 21) >> 21;
-                    const uint32_t slot = zpos + (e[k] >> 12);
+                    const uint32_t m = mk[k] > mexc ? mk[k] : mexc;
+                    const uint32_t slot = a_pos - m + (e[k] >> 12);
                     const bool term = (e[k] & 0xf7ffu) == 0;                     // EOB: completes the unit, stores nothing
                     if (!term && slot < 64) {
-                        const uint32_t kk = u % dus, comp = kk < nl ? 0 : kk - nl + 1;
+                        const uint32_t comp = comp_of[u];
                         if (slot == 52) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
                         else { const uint32_t qe = qz[comp][slot]; tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu); }
                     }
                 }
             }
-            zpos = last[k] ? 0u : zpos + adv[k];
+            a_pos += adv[k];
             u += last[k];
         }
-        run_agg = total;
+        // carry into the next chunk: units done; A - M at the chunk end (all threads compute the same)
+        {
+            uint32_t mall = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) mall = pjd_op_max(mall, wagg[it & 1][k][1]);
+            run_units += total >> 16;
+            run_tail = (total & 0xffffu) - mall;
+        }
         n += cnt;
-        it++;                                                   // the other copy of wagg next time: one barrier per chunk is enough
+        it++;                                                   // the other copy of wagg next time
     }
     __syncthreads();
 
@@ -510,27 +673,25 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     if (wv == 0) {
         const uint32_t d0 = wg.first_mcu * dus;
         uint32_t cy = pred0[0], cc = (pred0[1] & 0xffffu) | (pred0[2] << 16);   // predictors entering the next group of 64 units
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
         for (uint32_t base = 0; base < n_du; base += 64) {
             const uint32_t u = base + lane;
             const bool on = u < n_du;
             const uint32_t d = d0 + u, m = d / dus, kk = d - m * dus, comp = kk < nl ? 0 : kk - nl + 1;
             const uint32_t dv = on ? (uint32_t)dcraw[on ? u : 0] & 0xffffu : 0u;
+            const bool head = on && kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
+            // sums since the group start (inclusive), Y | Cb, Cr packed; then the same sums at the last head at or before the unit
             uint32_t vy = comp == 0 ? dv : 0u, vc = comp == 1 ? dv : (comp == 2 ? dv << 16 : 0u);
-            uint32_t hf = (on && kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0))) ? 1u : 0u;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t oy = __shfl_up(vy, off), oc = __shfl_up(vc, off), of = __shfl_up(hf, off);
-                if ((int)lane >= off) {
-                    if (!hf) {
-                        vy += oy;
-                        vc = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, vc) + __builtin_bit_cast(u16x2, oc)));
-                    }
-                    hf |= of;
-                }
-            }
-            // inclusive sums since the last head (or since the group start): add what entered the group
+            PJD_WAVE_SCAN(pjd_op_add, vy);
+            PJD_WAVE_SCAN(pjd_op_pkadd, vc);
+            uint32_t hpos = head ? lane + 1 : 0u;               // 1 + lane of the last head at or before this unit
+            PJD_WAVE_SCAN(pjd_op_max, hpos);
+            // a head resets the predictors BEFORE its own difference is added: subtract the sums just before it
+            const uint32_t hl = hpos ? hpos - 1 : 0u;           // lane of that head
+            const uint32_t by = __shfl(vy, (int)hl) - __shfl(comp == 0 ? dv : 0u, (int)hl);
+            const uint32_t bc = __shfl(vc, (int)hl), bc_own = __shfl(comp == 1 ? dv : (comp == 2 ? dv << 16 : 0u), (int)hl);
             uint32_t ty = vy, tc = vc;
-            if (!hf) { ty += cy; tc = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, tc) + __builtin_bit_cast(u16x2, cc))); }
+            if (hpos) { ty -= by; tc = pjd_op_pksub(tc, pjd_op_pksub(bc, bc_own)); }
+            else { ty += cy; tc = pjd_op_pkadd(tc, cc); }
             if (on) {
                 const uint32_t dcv = comp == 0 ? ty : (comp == 1 ? tc : tc >> 16);
                 tile[u][0] = (int16_t)pjd_dequant((int)(int16_t)dcv, qz[comp][0] & 0xffffu);
@@ -539,7 +700,17 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             cy = __shfl(ty, 63); cc = __shfl(tc, 63);
         }
     }
-    pjd_tile_to_pixels<true>(tile, mcu_xy, B, im, wg, tid);
+    // ---- IDCT (reference src/decoder_dpu.c:210-321): rows, then columns; then colour
+    if (tid < wg.n_mcu) {                                   // grid position of each MCU: the only divisions
+        const uint32_t m = wg.first_mcu + tid, my = m / im.mcux;
+        mcu_xy[tid] = (my << 16) | (m - my * im.mcux);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) pjd_tile_row(tile, i >> 3, i & 7);
+    __syncthreads();
+    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) pjd_tile_col(tile, i >> 3, i & 7);
+    __syncthreads();
+    pjd_colour_dispatch(tile, mcu_xy, B, im, wg, tid);
 }
 
 void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b)

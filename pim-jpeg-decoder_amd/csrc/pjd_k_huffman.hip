@@ -171,12 +171,24 @@ struct BitWin {
     }
 };
 
-// Per data-unit phase c of the MCU (LDS, one table per wave): x = LDS byte offset of the DC table | AC table << 16,
-// y = next phase | component << 8 | this phase << 16.
-__device__ __forceinline__ uint2 phase_load(const uint8_t *ptab, uint32_t c)
-{
-    return *reinterpret_cast<const uint2 *>(ptab + c * 8);
-}
+// Data-unit phase inside the MCU, kept as r = units of the MCU still to come after the current one (dus-1 .. 0):
+// the luma units come first, so the component is 0 while r >= nc (nc = chroma components), else nc - r.  The table
+// offsets (LDS byte offset of the DC table | AC table << 16) of the three components are wave-uniform.
+struct PhaseCtx {
+    uint32_t tY, tC1, tC2;     // wave-uniform
+    uint32_t nc, dus1;         // chroma components; data units per MCU - 1
+    // v_cndmask by hand: written as nested ?: the compiler builds a three-entry table in scratch memory and loads from it
+    static __device__ __forceinline__ uint32_t sel(bool c, uint32_t t, uint32_t f)
+    {
+        uint32_t d;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(__builtin_amdgcn_ballot_w64(c)));
+        return d;
+    }
+    // the last unit of the MCU (r == 0) belongs to the last component (tC2 == tC1 when there is one chroma component)
+    __device__ __forceinline__ uint32_t tabs(uint32_t r) const { return sel(r >= nc, tY, sel(r == 0, tC2, tC1)); }
+    __device__ __forceinline__ uint32_t comp(uint32_t r) const { return r >= nc ? 0u : nc - r; }
+    __device__ __forceinline__ uint32_t next(uint32_t r) const { return r == 0 ? dus1 : r - 1; }
+};
 
 struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided by lane)
     uint32_t *state;       // [PJD_NCHK][64] at this lane's column
@@ -206,25 +218,41 @@ __device__ __forceinline__ uint32_t lut_lookup(const uint8_t *lds, uint32_t tab,
 // the state equals the checkpoint recorded by an earlier pass (then ndu already includes the units still to
 // come); otherwise (re)write the checkpoints passed.  Returns the number of checkpoints passed + 1 in `jout`.
 template <bool BRIDGE>
-__device__ __forceinline__ int sync_span(const uint8_t *lds, const uint8_t *ptab, pjd_gptr wave_words, uint32_t lane,
+__device__ __forceinline__ int sync_span(const uint8_t *lds, const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
                                          uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
-                                         uint32_t &ndu, uint32_t &err, const ChkCtx &K, uint32_t &jout)
+                                         uint32_t &ndu, const ChkCtx &K, uint32_t &jout)
 {
     uint32_t j = 1;
     jout = 1;
     if (p >= end_bit) return SPAN_END;
     BitWin w;
     w.init(wave_words, lane, p);
-    uint2 cur = phase_load(ptab, c);
-    uint2 nx = phase_load(ptab, cur.y & 0xffu);
+    uint32_t r = P.dus1 - c;
+    uint32_t x = P.tabs(r);
     uint32_t next_chk = K.chk_bits;
     uint32_t lim = next_chk < end_bit ? next_chk : end_bit;     // one compare per symbol covers "subsequence end" and "next checkpoint"
-    uint32_t ov = 0;
     int res = SPAN_END;
+    // on entry p < lim: p <= 26 bits (a symbol that started before the lane's first byte) and p < end_bit
     for (;;) {
+        const uint32_t pk = w.peek();
+        const uint32_t tab = (z == 0) ? (x & 0xffffu) : (x >> 16);
+        const uint32_t e = lut_lookup(lds, tab, pk);
+        const uint32_t used = PJD_LUT_USED(e);
+        w.drop(used);
+        p += used;
+        // state update without branches (reference src/jpeg_scanner.cpp:469-518): a DC symbol has run 0 and
+        // never carries the EOB bit, so z -> z + run + 1 covers it; a run past slot 63 ends the unit here (the
+        // write pass reports it)
+        const uint32_t z1 = z + PJD_LUT_RUN(e) + 1;
+        const bool done = (((e >> 7) & 64u) | z1) > 63u;                    // EOB, or the unit's last slot was filled
+        const uint32_t rn = P.next(r);
+        z = done ? 0u : z1;
+        r = done ? rn : r;
+        x = done ? P.tabs(rn) : x;
+        ndu += done ? 1u : 0u;
         if (p >= lim) {
             if (p >= end_bit) break;
-            const uint32_t st = (p << 12) | ((cur.y >> 16) << 8) | z;      // p < 2^14, c < 16, z < 64
+            const uint32_t st = (p << 12) | (r << 8) | z;                  // p < 2^14, r < 16, z < 64
             if (BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
             K.state[j * 64] = st;
             K.rem[j * 64] = ndu;                                            // turned into "still to come" after the pass
@@ -232,26 +260,8 @@ __device__ __forceinline__ int sync_span(const uint8_t *lds, const uint8_t *ptab
             next_chk += K.chk_bits;
             lim = next_chk < end_bit ? next_chk : end_bit;
         }
-        const uint32_t pk = w.peek();
-        const uint32_t tab = (z == 0) ? (cur.x & 0xffffu) : (cur.x >> 16);
-        const uint32_t e = lut_lookup(lds, tab, pk);
-        const uint32_t used = PJD_LUT_USED(e);
-        w.drop(used);
-        p += used;
-        err |= e;
-        // state update without branches (reference src/jpeg_scanner.cpp:469-518): a DC symbol has run 0 and
-        // never carries the EOB bit, so z -> z + run + 1 covers it
-        const uint32_t z1 = z + PJD_LUT_RUN(e) + 1;
-        ov |= z1 + 63;                                                      // bit 7: run past slot 63 (jpeg_scanner.cpp:500)
-        const bool done = (((e >> 7) & 64u) | z1) > 63u;                    // EOB, or the unit's last slot was filled
-        z = done ? 0u : z1;
-        cur.x = done ? nx.x : cur.x;
-        cur.y = done ? nx.y : cur.y;
-        nx = phase_load(ptab, cur.y & 0xffu);
-        ndu += done ? 1u : 0u;
     }
-    err |= (ov & 0x80u) << 7;                                               // -> PJD_LUT_ERR
-    c = cur.y >> 16;
+    c = P.dus1 - r;
     jout = j;
     return res;
 }
@@ -287,8 +297,8 @@ __device__ __forceinline__ void stage_flush(const OutCtx &O, uint32_t first_entr
 }
 
 // One symbol of the write pass.  Returns the 16-bit entry; updates the state.
-__device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const uint8_t *ptab, BitWin &w, uint32_t &p, uint32_t &z,
-                                               uint2 &cur, uint2 &nx, uint32_t &err, uint32_t &ov, uint32_t &D, OutCtx &O)
+__device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const PhaseCtx &P, BitWin &w, uint32_t &p, uint32_t &z,
+                                               uint32_t &r, uint32_t &x, uint32_t &err, uint32_t &ov, uint32_t &D, OutCtx &O)
 {
     const bool is_dc = (z == 0);
     if (__builtin_expect(is_dc && O.left == 0, 0)) {                        // this unit opens an IDCT workgroup's range
@@ -299,7 +309,7 @@ __device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const uint8_t
         O.left = O.ru;
     }
     const uint32_t pk = w.peek();
-    const uint32_t tab = is_dc ? (cur.x & 0xffffu) : (cur.x >> 16);
+    const uint32_t tab = is_dc ? (x & 0xffffu) : (x >> 16);
     const uint32_t e = lut_lookup(lds, tab, pk);
     const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e), run = PJD_LUT_RUN(e);
     // value: `size` bits after the code, sign-extended the JPEG way (jpeg_scanner.cpp:478-484,510-516)
@@ -310,13 +320,13 @@ __device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const uint8_t
     p += used;
     err |= e;
     const uint32_t z1 = z + run + 1;
-    ov |= z1 + 63;
+    ov |= z1 + 63;                                                          // bit 7: run past slot 63 (jpeg_scanner.cpp:500)
     const bool done = (((e >> 7) & 64u) | z1) > 63u;
     // entry (layout: pjd_internal.h); the field above the value is the run, or bit 11 of a DC difference
     const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : run;
     const uint32_t ent = ((uint32_t)val & 0x7ffu) | (top << 12) | (done ? PJD_ENT_LAST : 0u);
     // DC sums of this lane, per component (the predictors come from a scan over lanes)
-    const uint32_t comp = (cur.y >> 8) & 3u;
+    const uint32_t comp = P.comp(r);
     const uint32_t dv = is_dc ? (uint32_t)val & 0xffffu : 0u;
     O.dcY += comp == 0 ? dv : 0u;
     {
@@ -325,10 +335,10 @@ __device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const uint8_t
         const u16x2 a = __builtin_bit_cast(u16x2, O.dcC), b = __builtin_bit_cast(u16x2, addc);
         O.dcC = __builtin_bit_cast(uint32_t, (u16x2)(a + b));
     }
+    const uint32_t rn = P.next(r);
     z = done ? 0u : z1;
-    cur.x = done ? nx.x : cur.x;
-    cur.y = done ? nx.y : cur.y;
-    nx = phase_load(ptab, cur.y & 0xffu);
+    r = done ? rn : r;
+    x = done ? P.tabs(rn) : x;
     D += done ? 1u : 0u;
     O.left -= done ? 1u : 0u;
     return ent;
@@ -337,21 +347,21 @@ __device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const uint8_t
 // Decodes from (p, c, z) until end_bit or until the segment's last data unit is complete (D == D_end).
 // Every active lane emits exactly one entry per step, so the entry count is the same in all of them and the
 // staging buffer is flushed by the whole wave at once.
-__device__ __forceinline__ void write_span(const uint8_t *lds, const uint8_t *ptab, pjd_gptr wave_words, uint32_t lane,
+__device__ __forceinline__ void write_span(const uint8_t *lds, const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
                                            uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                            uint32_t &err, uint32_t &D, uint32_t D_end, OutCtx &O)
 {
     BitWin w;
     w.init(wave_words, lane, p);
-    uint2 cur = phase_load(ptab, c);
-    uint2 nx = phase_load(ptab, cur.y & 0xffu);
+    uint32_t r = P.dus1 - c;
+    uint32_t x = P.tabs(r);
     uint32_t ov = 0;
     for (;;) {
         if (p >= end_bit || D >= D_end) break;
-        const uint32_t e0 = write_step(lds, ptab, w, p, z, cur, nx, err, ov, D, O);
+        const uint32_t e0 = write_step(lds, P, w, p, z, r, x, err, ov, D, O);
         O.n++;
         if (p >= end_bit || D >= D_end) { O.stage[((O.n >> 1) & 15u) * 64] = e0; break; }
-        const uint32_t e1 = write_step(lds, ptab, w, p, z, cur, nx, err, ov, D, O);
+        const uint32_t e1 = write_step(lds, P, w, p, z, r, x, err, ov, D, O);
         O.stage[((O.n >> 1) & 15u) * 64] = e0 | (e1 << 16);
         O.n++;
         if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {
@@ -361,7 +371,7 @@ __device__ __forceinline__ void write_span(const uint8_t *lds, const uint8_t *pt
     }
     if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
     err |= (ov & 0x80u) << 7;
-    c = cur.y >> 16;
+    c = P.dus1 - r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,14 +387,14 @@ struct LaneGeom {
     pjd_gptr words;                // wave-uniform: row 0 of the wave's transposed word rows
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][phase tables 4 x 64 B][wave areas 4 x PJD_WAVE_LDS][ticket]
+extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][wave areas 4 x PJD_WAVE_LDS][ticket]
 
 // Lanes have different origins, so states are exchanged as bit positions relative to the image's ecs.
 struct WaveState { uint32_t p_img, cz, cnt; };
 
 // Re-sync rounds inside one wave.  `changed`: this lane's exit state is new to its successor.  Lane 0 takes its
 // predecessor's exit from (ext_p, ext_cz) in the first round if `ext_new`.
-__device__ __forceinline__ bool wave_rounds(const uint8_t *ptab, const LaneGeom &g, const ChkCtx &K, WaveState &S, uint32_t changed,
+__device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g, const ChkCtx &K, WaveState &S, uint32_t changed,
                                             uint32_t ext_p, uint32_t ext_cz, bool ext_new, uint32_t &err_acc,
                                             unsigned long long *stats, int stat_base, uint32_t *rdbg)
 {
@@ -399,15 +409,14 @@ __device__ __forceinline__ bool wave_rounds(const uint8_t *ptab, const LaneGeom 
         if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)__popcll(act_mask)); }
         changed = 0;
         if (act) {
-            uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, err = 0, j;
-            const int res = sync_span<true>(pjd_huff_lds, ptab, g.words, l, p, c, z, g.end_bit, ndu, err, K, j);
+            uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, j;
+            const int res = sync_span<true>(pjd_huff_lds, P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
             chk_finish(K, j, ndu);               // also after a merge: ndu then includes the units still to come
             S.cnt = ndu;
             if (res != SPAN_MERGED) {
                 const uint32_t np = p + g.base_bit, ncz = (c << 8) | z;
                 if (np != S.p_img || ncz != S.cz) { S.p_img = np; S.cz = ncz; changed = 1; }
             }
-            (void)err;                       // irregular symbols on a trajectory that is not final say nothing
         }
         if (rdbg && l == 0 && iter < 24) rdbg[iter] = ((uint32_t)__popcll(act_mask) << 24) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - tr0) & 0xffffffu);
     }
@@ -498,8 +507,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
 {
     const uint32_t t = threadIdx.x, l = t & 63, wi = t >> 6;
     uint8_t *lds = pjd_huff_lds;
-    uint8_t *ptab_all = lds + B.max_lut_bytes;
-    uint8_t *areas = ptab_all + PJD_HUFF_WAVES * 64;
+    uint8_t *areas = lds + B.max_lut_bytes;
     uint32_t *tick = reinterpret_cast<uint32_t *>(areas + PJD_HUFF_WAVES * PJD_WAVE_LDS);
     if (t == 0) *tick = atomicAdd(B.ticket, 1u);
     __syncthreads();
@@ -526,15 +534,16 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     const uint32_t w = wg.first_wave + (wave_on ? wi : 0u);
     const PjdDevHuffWave hw = B.hwaves[w];
     const PjdDevImage &im = B.images[hw.image];
-    uint8_t *ptab = ptab_all + wi * 64;
-    const uint32_t nl = rfl(im.n_luma), dus = rfl(im.dus_per_mcu);
-    if (wave_on && l < dus) {                                  // phase table of this wave's image
-        const uint32_t comp = (l >= nl ? 1u : 0u) + (l > nl ? 1u : 0u);
-        uint2 e;
-        e.x = (uint32_t)im.tbl_slot[comp][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[comp][1] * PJD_L1_BYTES) << 16;
-        e.y = (l + 1 == dus ? 0u : l + 1) | (comp << 8) | (l << 16);
-        *reinterpret_cast<uint2 *>(ptab + l * 8) = e;
+    PhaseCtx P;                                                // table offsets of this wave's image (blob at LDS offset 0)
+    {
+        const uint32_t nl = rfl(im.n_luma), dus = rfl(im.dus_per_mcu), nc = dus - nl;
+        const uint32_t c1 = nc >= 1 ? 1u : 0u, c2 = nc >= 2 ? 2u : c1;
+        P.tY  = rfl((uint32_t)im.tbl_slot[0][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[0][1] * PJD_L1_BYTES) << 16);
+        P.tC1 = rfl((uint32_t)im.tbl_slot[c1][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[c1][1] * PJD_L1_BYTES) << 16);
+        P.tC2 = rfl((uint32_t)im.tbl_slot[c2][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[c2][1] * PJD_L1_BYTES) << 16);
+        P.nc = nc; P.dus1 = dus - 1;
     }
+    const uint32_t dus = P.dus1 + 1;
     __syncthreads();                                           // the last barrier: from here on waves run on their own
     if (!wave_on) return;
 
@@ -574,9 +583,9 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     // ---- A: speculative pass
     WaveState S;
     {
-        uint32_t p = 0, c = 0, z = 0, ndu = 0, err = 0, j = 1;
+        uint32_t p = 0, c = 0, z = 0, ndu = 0, j = 1;
         if (g.valid) {
-            sync_span<false>(lds, ptab, g.words, l, p, c, z, g.end_bit, ndu, err, K, j);
+            sync_span<false>(lds, P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
             chk_finish(K, j, ndu);
         }
         S.p_img = p + g.base_bit; S.cz = (c << 8) | z; S.cnt = ndu;
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     uint32_t err_acc = 0;
     bool ok = true;
     if (!first_is_head) entry_used = op_wait_flag(genA + w - 1, dead);
-    ok = wave_rounds(ptab, g, K, S, g.valid ? 1u : 0u, (uint32_t)entry_used,
+    ok = wave_rounds(P, g, K, S, g.valid ? 1u : 0u, (uint32_t)entry_used,
                      (((uint32_t)(entry_used >> 32) & 255) << 8) | ((uint32_t)(entry_used >> 40) & 255), !first_is_head && !dead,
                      err_acc, B.stats, 0, B.dbg ? B.dbg + (size_t)w * 32 + 8 : nullptr);
     if (l == last_lane) op_store(genB + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         const uint64_t truth = op_wait_flag(genB + w - 1, dead);
         if (!dead && truth != entry_used) {
             entry_used = truth;
-            ok = wave_rounds(ptab, g, K, S, 0u, (uint32_t)truth,
+            ok = wave_rounds(P, g, K, S, 0u, (uint32_t)truth,
                              (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255), true,
                              err_acc, B.stats, 2, nullptr) && ok;
         }
@@ -693,7 +702,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 O.left = first_du + k * O.ru - D_in;
             }
             uint32_t err = 0;
-            write_span(lds, ptab, g.words, l, p, c, z, g.end_bit, err, D, D_end, O);
+            write_span(lds, P, g.words, l, p, c, z, g.end_bit, err, D, D_end, O);
             li.n_ent = O.n;
             li.dc_sum[0] = (uint16_t)O.dcY; li.dc_sum[1] = (uint16_t)O.dcC; li.dc_sum[2] = (uint16_t)(O.dcC >> 16);
             if (err & PJD_LUT_ERR) flag |= 1u << PJD_FLAG_SYMBOL;
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + PJD_HUFF_WAVES * 64 + PJD_HUFF_WAVES * PJD_WAVE_LDS + 16; }
+static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + PJD_HUFF_WAVES * PJD_WAVE_LDS + 16; }
 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 {

@@ -41,7 +41,9 @@ static float vnoise(uint64_t seed, float x, float y)
 /* Per (channel, octave) the lattice is tabulated once; a pixel then costs 4 reads per octave. */
 typedef struct { float *g; int gx, gy; float inv; } octave;
 
-void synth_picture(uint8_t *rgb, int w, int h, uint64_t seed)
+/* detail: 1.0 = the round-1 pictures (~0.32 B/px at q75-95 4:2:0); larger values add fine luminance texture and grain,
+ * ~2.2 gives the density of the bundled ImageNet sample's class (~0.58 B/px) */
+void synth_picture2(uint8_t *rgb, int w, int h, uint64_t seed, float detail)
 {
     enum { NOCT = 6 };
     uint64_t s = mix64(seed);
@@ -97,7 +99,7 @@ void synth_picture(uint8_t *rgb, int w, int h, uint64_t seed)
                 if (a > 0) for (int c = 0; c < 3; c++) v[c] = v[c] * (1 - 0.8f * a) + sc[k][c] * 0.8f * a;
             }
             uint64_t n = mix64(s ^ ((uint64_t)y * 65537u + x));
-            const float ln = ((float)(n & 0xFFFF) / 65536.0f - 0.5f) * 26.0f;      /* luminance grain */
+            const float ln = ((float)(n & 0xFFFF) / 65536.0f - 0.5f) * 26.0f * detail;      /* luminance grain */
             for (int c = 0; c < 3; c++) {
                 float t = (v[c] - 128.0f) * 1.6f + 128.0f + ln + ((float)((n >> (16 * (c + 1))) & 0xFFFF) / 65536.0f - 0.5f) * 4.0f;
                 rgb[((size_t)y * w + x) * 3 + c] = (uint8_t)(t < 0 ? 0 : (t > 255 ? 255 : t));
@@ -105,6 +107,8 @@ void synth_picture(uint8_t *rgb, int w, int h, uint64_t seed)
         }
     for (int c = 0; c < 3; c++) for (int o = 0; o < NOCT; o++) free(oc[c][o].g);
 }
+
+void synth_picture(uint8_t *rgb, int w, int h, uint64_t seed) { synth_picture2(rgb, w, h, seed, 1.0f); }
 
 /* ---- encoder ------------------------------------------------------------------------------ */
 static const uint8_t zz[64] = {
@@ -207,7 +211,50 @@ static void fdct(const float *in, float *out)
 
 static int bitsize(int v) { int a = v < 0 ? -v : v, n = 0; while (a) { n++; a >>= 1; } return n; }
 
-static void encode_block(bitw *b, const float *px, const uint8_t *q, int *pred, const hcode *dc, const hcode *ac)
+/* Optimal (length-limited to 16) Huffman code lengths from symbol frequencies: ITU-T T.81 Annex K.2, as every
+ * optimising encoder does it.  freq[256] is the reserved all-ones code point. */
+static void gen_optimal_table(long *freq, uint8_t *bits /*16*/, uint8_t *vals /*<=256*/, int *nvals)
+{
+    int codesize[257], others[257];
+    uint8_t nb[33];
+    memset(codesize, 0, sizeof codesize);
+    memset(nb, 0, sizeof nb);
+    for (int i = 0; i < 257; i++) others[i] = -1;
+    freq[256] = 1;
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        long v = 1000000000L;
+        for (int i = 0; i <= 256; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        v = 1000000000L;
+        for (int i = 0; i <= 256; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2]; freq[c2] = 0;
+        codesize[c1]++;
+        while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+        others[c1] = c2;
+        codesize[c2]++;
+        while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+    }
+    for (int i = 0; i <= 256; i++) if (codesize[i]) nb[codesize[i] > 32 ? 32 : codesize[i]]++;
+    for (int i = 32; i > 16; i--)
+        while (nb[i] > 0) {
+            int j = i - 2;
+            while (nb[j] == 0) j--;
+            nb[i] -= 2; nb[i - 1]++;
+            nb[j + 1] += 2; nb[j]--;
+        }
+    int i = 16;
+    while (nb[i] == 0) i--;
+    nb[i]--;                                           /* drop the reserved code point */
+    for (int k = 0; k < 16; k++) bits[k] = nb[k + 1];
+    int p = 0;
+    for (int l = 1; l <= 32; l++)
+        for (int k = 0; k <= 255; k++) if (codesize[k] == l) vals[p++] = (uint8_t)k;
+    *nvals = p;
+}
+
+/* stats != NULL: count the symbols (stats[0] = DC table, stats[1] = AC table, 257 counters each) instead of writing them */
+static void encode_block(bitw *b, const float *px, const uint8_t *q, int *pred, const hcode *dc, const hcode *ac, long (*stats)[257])
 {
     float f[64];
     int c[64];
@@ -222,25 +269,36 @@ static void encode_block(bitw *b, const float *px, const uint8_t *q, int *pred, 
     int diff = c[0] - *pred;
     *pred = c[0];
     int s = bitsize(diff);
-    put_bits(b, dc->code[s], dc->len[s]);
-    if (s) put_bits(b, (uint32_t)(diff < 0 ? diff - 1 : diff), s);
+    if (stats) stats[0][s]++;
+    else {
+        put_bits(b, dc->code[s], dc->len[s]);
+        if (s) put_bits(b, (uint32_t)(diff < 0 ? diff - 1 : diff), s);
+    }
     int run = 0;
     for (int k = 1; k < 64; k++) {
         if (c[k] == 0) { run++; continue; }
-        while (run > 15) { put_bits(b, ac->code[0xF0], ac->len[0xF0]); run -= 16; }
+        while (run > 15) { if (stats) stats[1][0xF0]++; else put_bits(b, ac->code[0xF0], ac->len[0xF0]); run -= 16; }
         s = bitsize(c[k]);
         int sym = (run << 4) | s;
-        put_bits(b, ac->code[sym], ac->len[sym]);
-        put_bits(b, (uint32_t)(c[k] < 0 ? c[k] - 1 : c[k]), s);
+        if (stats) stats[1][sym]++;
+        else {
+            put_bits(b, ac->code[sym], ac->len[sym]);
+            put_bits(b, (uint32_t)(c[k] < 0 ? c[k] - 1 : c[k]), s);
+        }
         run = 0;
     }
-    if (run) put_bits(b, ac->code[0], ac->len[0]);
+    if (run) { if (stats) stats[1][0]++; else put_bits(b, ac->code[0], ac->len[0]); }
 }
 
 /* subsampling: 0 = 4:4:4, 1 = 4:2:2 (h2v1), 2 = 4:2:0, 3 = 4:4:0 (h1v2), 4 = grey.
  * Returns the number of bytes written, or -1 if `cap` was too small. */
-long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling, int restart_interval,
-                  uint8_t *out, long cap)
+static long scan_pass(bitw *pb, const uint8_t *rgb, int w, int h, int H, int V, int grey, int restart_interval,
+                      const uint8_t *ql, const uint8_t *qc, const hcode *hdl, const hcode *hal, const hcode *hdc, const hcode *hac,
+                      long (*st_l)[257], long (*st_c)[257]);
+
+/* optimize != 0: two passes, Huffman tables fitted to this picture (4 distinct tables, as the bundled ImageNet sample has) */
+long synth_encode2(const uint8_t *rgb, int w, int h, int quality, int subsampling, int restart_interval, int optimize,
+                   uint8_t *out, long cap)
 {
     const int grey = subsampling == 4;
     const int H = (subsampling == 1 || subsampling == 2) ? 2 : 1;
@@ -255,9 +313,22 @@ long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling
         ql[k] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
         qc[k] = (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
     }
+    uint8_t tb[4][16], tv[4][256];                      /* 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma */
+    memcpy(tb[0], bits_dc_l, 16); memcpy(tv[0], val_dc, 12);
+    memcpy(tb[1], bits_ac_l, 16); memcpy(tv[1], val_ac_l, 162);
+    memcpy(tb[2], bits_dc_c, 16); memcpy(tv[2], val_dc, 12);
+    memcpy(tb[3], bits_ac_c, 16); memcpy(tv[3], val_ac_c, 162);
+    if (optimize) {
+        long st_l[2][257], st_c[2][257];
+        memset(st_l, 0, sizeof st_l); memset(st_c, 0, sizeof st_c);
+        scan_pass(NULL, rgb, w, h, H, V, grey, restart_interval, ql, qc, NULL, NULL, NULL, NULL, st_l, st_c);
+        int nv;
+        gen_optimal_table(st_l[0], tb[0], tv[0], &nv); gen_optimal_table(st_l[1], tb[1], tv[1], &nv);
+        if (!grey) { gen_optimal_table(st_c[0], tb[2], tv[2], &nv); gen_optimal_table(st_c[1], tb[3], tv[3], &nv); }
+    }
     hcode hdl, hdc, hal, hac;
-    build_codes(bits_dc_l, val_dc, &hdl); build_codes(bits_dc_c, val_dc, &hdc);
-    build_codes(bits_ac_l, val_ac_l, &hal); build_codes(bits_ac_c, val_ac_c, &hac);
+    build_codes(tb[0], tv[0], &hdl); build_codes(tb[2], tv[2], &hdc);
+    build_codes(tb[1], tv[1], &hal); build_codes(tb[3], tv[3], &hac);
 
     bitw b = { out, (size_t)cap, 0, 0, 0, 0 };
     put16(&b, 0xFFD8);
@@ -270,8 +341,7 @@ long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling
     put_byte(&b, 1); put_byte(&b, (uint8_t)((H << 4) | V)); put_byte(&b, 0);
     if (!grey) { put_byte(&b, 2); put_byte(&b, 0x11); put_byte(&b, 1); put_byte(&b, 3); put_byte(&b, 0x11); put_byte(&b, 1); }
     for (int t = 0; t < (grey ? 2 : 4); t++) {
-        const uint8_t *bits = t == 0 ? bits_dc_l : t == 1 ? bits_ac_l : t == 2 ? bits_dc_c : bits_ac_c;
-        const uint8_t *vals = t == 0 ? val_dc : t == 1 ? val_ac_l : t == 2 ? val_dc : val_ac_c;
+        const uint8_t *bits = tb[t], *vals = tv[t];
         int n = 0;
         for (int k = 0; k < 16; k++) n += bits[k];
         put16(&b, 0xFFC4); put16(&b, 19 + n);
@@ -285,6 +355,16 @@ long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling
     if (!grey) { put_byte(&b, 2); put_byte(&b, 0x11); put_byte(&b, 3); put_byte(&b, 0x11); }
     put_byte(&b, 0); put_byte(&b, 63); put_byte(&b, 0);
 
+    scan_pass(&b, rgb, w, h, H, V, grey, restart_interval, ql, qc, &hdl, &hal, &hdc, &hac, NULL, NULL);
+    flush_bits(&b);
+    put16(&b, 0xFFD9);
+    return b.overflow ? -1 : (long)b.n;
+}
+
+static long scan_pass(bitw *pb, const uint8_t *rgb, int w, int h, int H, int V, int grey, int restart_interval,
+                      const uint8_t *ql, const uint8_t *qc, const hcode *hdl, const hcode *hal, const hcode *hdc, const hcode *hac,
+                      long (*st_l)[257], long (*st_c)[257])
+{
     const int mw = 8 * H, mh = 8 * V;
     const int mcux = (w + mw - 1) / mw, mcuy = (h + mh - 1) / mh;
     int pred[3] = { 0, 0, 0 }, count = 0, rst = 0;
@@ -292,8 +372,8 @@ long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling
     for (int my = 0; my < mcuy; my++)
         for (int mx = 0; mx < mcux; mx++) {
             if (restart_interval > 0 && count == restart_interval) {
-                flush_bits(&b);
-                put_byte(&b, 0xFF); put_byte(&b, (uint8_t)(0xD0 + (rst++ & 7)));
+                if (pb) flush_bits(pb);
+                if (pb) { put_byte(pb, 0xFF); put_byte(pb, (uint8_t)(0xD0 + (rst++ & 7))); }
                 pred[0] = pred[1] = pred[2] = 0;
                 count = 0;
             }
@@ -312,7 +392,7 @@ long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling
             for (int v = 0; v < V; v++)
                 for (int hh = 0; hh < H; hh++) {
                     for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) blk[y * 8 + x] = Y[(v * 8 + y) * 16 + hh * 8 + x];
-                    encode_block(&b, blk, ql, &pred[0], &hdl, &hal);
+                    encode_block(pb, blk, ql, &pred[0], hdl, hal, st_l);
                 }
             if (!grey)
                 for (int c = 1; c < 3; c++) {
@@ -323,12 +403,16 @@ long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling
                             for (int v = 0; v < V; v++) for (int hh = 0; hh < H; hh++) s += src[(y * V + v) * 16 + x * H + hh];
                             blk[y * 8 + x] = s / (H * V);
                         }
-                    encode_block(&b, blk, qc, &pred[c], &hdc, &hac);
+                    encode_block(pb, blk, qc, &pred[c], hdc, hac, st_c);
                 }
         }
-    flush_bits(&b);
-    put16(&b, 0xFFD9);
-    return b.overflow ? -1 : (long)b.n;
+    return 0;
+}
+
+long synth_encode(const uint8_t *rgb, int w, int h, int quality, int subsampling, int restart_interval,
+                  uint8_t *out, long cap)
+{
+    return synth_encode2(rgb, w, h, quality, subsampling, restart_interval, 0, out, cap);
 }
 
 /* convenience: picture + encode in one call (thread-safe once ctab is initialised) */
@@ -338,6 +422,17 @@ long synth_make(int w, int h, uint64_t seed, int quality, int subsampling, int r
     if (!rgb) return -1;
     synth_picture(rgb, w, h, seed);
     long n = synth_encode(rgb, w, h, quality, subsampling, restart_interval, out, cap);
+    free(rgb);
+    return n;
+}
+
+long synth_make2(int w, int h, uint64_t seed, int quality, int subsampling, int restart_interval, int detail_x100, int optimize,
+                 uint8_t *out, long cap)
+{
+    uint8_t *rgb = (uint8_t *)malloc((size_t)w * h * 3);
+    if (!rgb) return -1;
+    synth_picture2(rgb, w, h, seed, detail_x100 / 100.0f);
+    long n = synth_encode2(rgb, w, h, quality, subsampling, restart_interval, optimize, out, cap);
     free(rgb);
     return n;
 }

@@ -34,6 +34,10 @@ def lib():
         L.synth_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
         L.synth_make.restype = C.c_long
         L.synth_make.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
+        L.synth_make2.restype = C.c_long
+        L.synth_make2.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
+        L.synth_encode2.restype = C.c_long
+        L.synth_encode2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
         L.synth_init()
         _lib = L
     return _lib
@@ -45,20 +49,22 @@ def picture(w, h, seed):
     return rgb
 
 
-def encode(rgb, quality=85, subsampling=SUB_420, restart_interval=0):
+def encode(rgb, quality=85, subsampling=SUB_420, restart_interval=0, optimize=False):
     h, w, _ = rgb.shape
     rgb = np.ascontiguousarray(rgb)
     cap = w * h * 3 + 4096
     out = np.zeros(cap, np.uint8)
-    n = lib().synth_encode(rgb.ctypes.data, w, h, quality, subsampling, restart_interval, out.ctypes.data, cap)
+    n = lib().synth_encode2(rgb.ctypes.data, w, h, quality, subsampling, restart_interval, int(optimize), out.ctypes.data, cap)
     assert n > 0
     return out[:n].tobytes()
 
 
-def make(w, h, seed, quality=85, subsampling=SUB_420, restart_interval=0):
+def make(w, h, seed, quality=85, subsampling=SUB_420, restart_interval=0, detail=1.0, optimize=False):
+    """detail 1.0 = the round-1 pictures (~0.32 B/px at q75-95 4:2:0); DENSE_DETAIL gives the density of the bundled
+    ImageNet sample's class (~0.58 B/px).  optimize: Huffman tables fitted to the picture (4 distinct tables)."""
     cap = w * h * 3 + 4096
     out = np.zeros(cap, np.uint8)
-    n = lib().synth_make(w, h, seed, quality, subsampling, restart_interval, out.ctypes.data, cap)
+    n = lib().synth_make2(w, h, seed, quality, subsampling, restart_interval, int(round(detail * 100)), int(optimize), out.ctypes.data, cap)
     assert n > 0
     return out[:n].tobytes()
 
@@ -77,12 +83,20 @@ def imagenet_like_specs(n, seed=3):
     return specs
 
 
-def cfg3_imagenet_like(n=1024, seed=3, threads=None):
+DENSE_DETAIL = 2.2      # calibrated in tests/test_synth.py: mean density of the cfg3 set >= 0.55 B/px
+
+
+def cfg3_imagenet_like(n=1024, seed=3, threads=None, detail=1.0, optimize=False, extra=()):
+    """n mixed-size 4:2:0 JPEGs.  `extra`: RGB arrays re-encoded (4:2:0, q90) in place of the first pictures of the set --
+    the bench puts the bundled ImageNet sample there."""
     lib()
     specs = imagenet_like_specs(n, seed)
     threads = threads or min(16, os.cpu_count() or 4)
     with ThreadPoolExecutor(threads) as ex:      # ctypes drops the GIL inside the C call
-        return list(ex.map(lambda s: make(s[0], s[1], s[2], s[3], SUB_420, 0), specs))
+        out = list(ex.map(lambda s: make(s[0], s[1], s[2], s[3], SUB_420, 0, detail, optimize), specs))
+    for k, rgb in enumerate(extra):
+        out[k] = encode(rgb, 90, SUB_420, 0, optimize)
+    return out
 
 
 def cfg2_single_4k(seed=2, restart_rows=False):
