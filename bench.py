@@ -7,8 +7,8 @@ One process per GPU (the driver launches N ranks with torch.distributed.run); ev
 OWN batch (weak scaling, no data-path collective: images are independent).  A step = one pass of the
 whole hot path (Huffman entropy decode -> dequantise -> IDCT -> upsample -> YCbCr->RGB) over one
 batch whose bitstreams, tables and work lists are already resident in HBM; pictures stay in HBM.
-By default two identical batches are resident and steps alternate between them, each batch on its own HIP stream
-(`--in-flight 2`), so step i is issued while step i-1 still runs -- a serving loop; every step's results are
+By default three identical batches are resident and steps rotate over them, each batch on its own HIP stream
+(`--in-flight 3`), so step i is issued while step i-1 still runs -- a serving loop; every step's results are
 drained and checked (`pjd_batch_sync`) before its batch is decoded again.  `one_batch_in_flight` reports the
 same K steps strictly serialised, and the per-kernel durations / `roofline` come from serialised launches too.
 Rank 0 prints ONE JSON line.  Beside the contract fields it carries `roofline` (dominant kernel: algorithmic
@@ -17,7 +17,11 @@ reference's own host code on one core, same JPEGs) and, at N=1, `pcie_inclusive`
 pipelined batcher (libpjdpipe) from JPEG bytes in host memory to BMP bytes in page-locked host memory -- never `value`.
 
 Workloads (synthetic and seeded -- there is no dataset on the box; tools/synth.py):
-    cfg3     M (default 1024) ImageNet-like 4:2:0 JPEGs of mixed sizes per GPU, hipGraph replay  [default]
+    cfg3     M (default 1024) ImageNet-like 4:2:0 JPEGs of mixed sizes per GPU, hipGraph replay  [default].  The set has the
+             density of the one real ImageNet file at hand (~0.58 B/px against its 0.58), every picture carries its own
+             optimised Huffman tables (four distinct ones, like that file), and picture 0 is that file re-encoded 4:2:0.
+             `variants` in the output line repeats the measurement on the lighter round-1 set (Annex-K tables, 0.32 B/px).
+    cfg3lite the round-1 set itself as the main workload
     cfg2     one 3840x2160 4:2:0 q85 JPEG without restart markers
     cfg2rst  the same picture with one restart interval per MCU row
     cfg5     one 8192x8192 4:4:4 JPEG, one restart interval per MCU row (size via --tile)
@@ -37,10 +41,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-def make_workload(name, n_images, seed, tile):
+def bundled_rgb(device):
+    """The bundled ImageNet sample as pixels, decoded by THIS library (the product, not the oracle)."""
+    import numpy as np
+    import pjd_amd
+    data = open(os.path.join(ROOT, "tests", "golden", "ilsvrc_val_00000001.jpg"), "rb").read()
+    s = pjd_amd.Scanned(data)
+    ctx = pjd_amd.Context(device)
+    outs, st = ctx.decode([s.desc], pjd_amd.OUT_RGB8)
+    ctx.close()
+    assert st == [0]
+    return np.asarray(outs[0]).reshape(int(s.desc.height), int(s.desc.width), 3)
+
+
+def make_workload(name, n_images, seed, tile, device=0):
     import synth
     if name == "cfg3":
-        return synth.cfg3_imagenet_like(n_images, seed=seed), f"{n_images} ImageNet-like 4:2:0 JPEGs (mixed sizes, q75-95, seed {seed}) per GPU, hipGraph replay"
+        jp = synth.cfg3_imagenet_like(n_images, seed=seed, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True,
+                                      extra=[bundled_rgb(device)])
+        return jp, (f"{n_images} ImageNet-like 4:2:0 JPEGs (mixed sizes, q88-97, per-picture optimised Huffman tables, seed {seed}; "
+                    "picture 0 = the bundled ImageNet sample re-encoded) per GPU, hipGraph replay")
+    if name == "cfg3lite":
+        return synth.cfg3_imagenet_like(n_images, seed=seed), f"{n_images} ImageNet-like 4:2:0 JPEGs (mixed sizes, q75-95, Annex-K tables, seed {seed}) per GPU, hipGraph replay"
     if name == "cfg2":
         return [synth.cfg2_single_4k(seed=seed)], "one 3840x2160 4:2:0 q85 JPEG, no restart markers"
     if name == "cfg2rst":
@@ -93,7 +115,7 @@ def cpu_baseline(jpegs, budget_s=12.0):
             # the same code on all host cores of this box's share: one image per task, threads (ctypes drops the GIL and
             # the reference's functions keep no static state) -- the reference itself is single-producer/single-consumer
             from concurrent.futures import ThreadPoolExecutor
-            threads = max(1, min(16, os.cpu_count() or 1))
+            threads = max(1, os.cpu_count() or 1)
             sample = jpegs[:n]
             for k, data in enumerate(sample):
                 with open(os.path.join(tmp, f"{k}.jpg"), "wb") as f:
@@ -107,6 +129,7 @@ def cpu_baseline(jpegs, budget_s=12.0):
                 rcs = list(ex.map(one, range(len(sample))))
             t_par = time.perf_counter() - t0
             assert not any(rcs)
+            out["host_nproc"] = os.cpu_count()
             out["all_cores"] = {"value": round(pix / t_par / 1e6, 2), "unit": "MPix/s", "cores": threads,
                                 "sample": f"the same {n} JPEGs, one image per task on {threads} threads ({t_par:.2f} s)"}
         return out
@@ -124,10 +147,13 @@ def main():
     ap.add_argument("--images", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=8192)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="resident batches decoded round-robin, each on its own HIP stream: step i is issued while step i-1 is "
                          "still running, as a serving loop would (1 = strictly one step after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra measurement on the lighter cfg3lite set")
+    ap.add_argument("--out-format", default="bmp", choices=["bmp", "rgb8"],
+                    help="what the device writes per picture: the BMP file image the reference's writer would emit (default), or tight RGB8")
     ap.add_argument("--verify", action="store_true", help="check a few pictures against the oracle after the run")
     ap.add_argument("--e2e-batches", type=int, default=16,
                     help="also run the pipelined batcher (JPEG bytes in host memory -> BMP bytes in pinned host memory, "
@@ -151,33 +177,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import pjd_amd
-    t_gen = time.perf_counter()
-    jpegs, label = make_workload(args.workload, args.images, 3 + rank, args.tile)
-    t_gen = time.perf_counter() - t_gen
-    t_scan = time.perf_counter()
-    scanned = [pjd_amd.Scanned(j) for j in jpegs]
-    t_scan = time.perf_counter() - t_scan
-    assert all(s.valid for s in scanned)
-    if args.workload == "cfg2rst":
-        # 4:2:0 + DRI: the reference's own restart rule garbles such files; decode per ITU-T.81
-        for s in scanned:
-            s.desc.flags = pjd_amd.F_STANDARD_RESTART
-
-    # One context = one HIP stream.  `--in-flight` identical batches are resident; step i decodes batch i % in_flight,
-    # so consecutive steps overlap (the slow tail of one step's entropy decode runs beside the next step's bulk).
+    out_fmt = pjd_amd.OUT_BMP if args.out_format == "bmp" else pjd_amd.OUT_RGB8
     nfl = max(1, args.in_flight)
-    ctxs = [pjd_amd.Context(local_rank) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing
-    batches = [c.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8) for c in ctxs]
-    ctx, batch = ctxs[0], batches[0]
-    t_up = time.perf_counter()
-    batch.upload()
-    t_up = time.perf_counter() - t_up
-    for b in batches[1:]:
-        b.upload()
-    info = batch.info()
-    if not args.no_graph:
-        for b in batches:
-            b.capture()
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,86 +197,152 @@ def main():
         for b in group[:min(n, g)]:
             b.sync()
 
-    run_steps(max(args.warmup, nfl), batches)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps, batches)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # the same K steps strictly one after the other (reported beside `value`, never instead of it)
-    dt_serial = None
-    if nfl > 1:
+    def measure(workload, steps, warmup, full):
+        """Generate `workload`, make `nfl` resident batches, time `steps` steps.  full: also the serialised run and the
+        per-kernel HIP-event timings."""
+        t_gen = time.perf_counter()
+        jpegs, label = make_workload(workload, args.images, 3 + rank, args.tile, local_rank)
+        t_gen = time.perf_counter() - t_gen
+        t_scan = time.perf_counter()
+        scanned = [pjd_amd.Scanned(j) for j in jpegs]
+        t_scan = time.perf_counter() - t_scan
+        assert all(s.valid for s in scanned)
+        if workload == "cfg2rst":
+            # 4:2:0 + DRI: the reference's own restart rule garbles such files (SURVEY 0.7); decode per ITU-T.81
+            for s in scanned:
+                s.desc.flags = pjd_amd.F_STANDARD_RESTART
+        # One context = one HIP stream.  `--in-flight` identical batches are resident; step i decodes batch i % in_flight,
+        # so consecutive steps overlap (the slow tail of one step's entropy decode runs beside the next step's bulk).
+        ctxs = [pjd_amd.Context(local_rank) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing
+        batches = [c.batch([s.desc for s in scanned], out_fmt) for c in ctxs]
+        batch = batches[0]
+        t_up = time.perf_counter()
+        batch.upload()
+        t_up = time.perf_counter() - t_up
+        for b in batches[1:]:
+            b.upload()
+        if not args.no_graph:
+            for b in batches:
+                b.capture()
+        run_steps(max(warmup, nfl), batches)
         barrier()
         t0 = time.perf_counter()
-        run_steps(args.steps, batches[:1])
+        run_steps(steps, batches)
         barrier()
-        dt_serial = time.perf_counter() - t0
-    info = batch.info()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        r = {"jpegs": jpegs, "label": label, "dt": dt, "steps": steps, "host_ms": {"generate": round(t_gen * 1e3, 1),
+             "scan": round(t_scan * 1e3, 1), "upload": round(t_up * 1e3, 1)}}
+        # the same K steps strictly one after the other (reported beside `value`, never instead of it)
+        if nfl > 1:
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(steps, batches[:1])
+            barrier()
+            r["dt_serial"] = time.perf_counter() - t0
+        r["info"] = batch.info()
+        if full:
+            # per-kernel durations, HIP events on the library's own stream (ungraphed launches of the same work)
+            ktimes, ktotal, reps = {}, 0.0, 5
+            for _ in range(reps):
+                kt, tot = batch.decode_timed()
+                batch.sync()
+                for k, v in kt.items():
+                    ktimes[k] = ktimes.get(k, 0.0) + v / reps
+                ktotal += tot / reps
+            r["ktimes"], r["ktotal"] = ktimes, ktotal
+            if args.verify and rank == 0:
+                import numpy as np
+                import oracle_lib
+                port = oracle_lib.Port()
+                outs, st = batch.download()
+                idx = list(range(min(4, len(jpegs))))
+                if out_fmt == pjd_amd.OUT_BMP:
+                    r["verify"] = all(outs[i].tobytes() == port.decode(jpegs[i])["bmp"] for i in idx)
+                else:
+                    r["verify"] = all(np.array_equal(outs[i], port.decode(jpegs[i])["rgb"]) for i in idx)
+        for b in batches:
+            b.destroy()
+        for c in ctxs:
+            c.close()
+        return r
 
-    # per-kernel durations, HIP events on the library's own stream (ungraphed launches of the same work)
-    ktimes, ktotal, reps = {}, 0.0, 5
-    if not args.no_graph:
-        pass
-    for _ in range(reps):
-        kt, tot = batch.decode_timed()
-        batch.sync()
-        for k, v in kt.items():
-            ktimes[k] = ktimes.get(k, 0.0) + v / reps
-        ktotal += tot / reps
+    def rates(r):
+        """Throughput figures of one measurement (whole job: all ranks)."""
+        info, dt, k = r["info"], r["dt"], r["steps"]
+        o = {"value": round(world * info["pixels"] * k / dt / 1e6, 2), "unit": "MPix/s", "ms_per_step": round(dt / k * 1e3, 4),
+             "ecs_GBps": round(world * info["ecs_bytes"] * k / dt / 1e9, 2),
+             "huffman_symbols_per_s": round(world * info["n_entries"] * k / dt, 0),
+             "bytes_per_pixel": round(info["ecs_bytes"] / info["pixels"], 3), "table_sets": info["n_table_sets"],
+             "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
+             "exact_kernel_images": info["n_sequential"] + info["n_fallback"]}
+        if "dt_serial" in r:
+            o["one_batch_in_flight"] = {"value": round(world * info["pixels"] * k / r["dt_serial"] / 1e6, 2), "unit": "MPix/s",
+                                        "ms_per_step": round(r["dt_serial"] / k * 1e3, 4)}
+        return o
 
-    verify = None
-    if args.verify and rank == 0:
-        import numpy as np
-        import oracle_lib
-        port = oracle_lib.Port()
-        outs, st = batch.download()
-        idx = list(range(min(4, len(jpegs))))
-        verify = all(np.array_equal(outs[i], port.decode(jpegs[i])["rgb"]) for i in idx)
+    R = measure(args.workload, args.steps, args.warmup, True)
+    variants = {}
+    if args.workload == "cfg3" and not args.no_variants:
+        # the lighter round-1 set, same run (Annex-K tables shared by every picture, 0.32 B/px)
+        V = measure("cfg3lite", max(5, args.steps // 2), args.warmup, False)
+        variants["cfg3lite"] = dict(rates(V), workload=V["label"])
 
     if rank == 0:
+        info, ktimes = R["info"], R["ktimes"]
+        main_rates = rates(R)
         pixels = info["pixels"]
-        value = world * pixels * args.steps / dt / 1e6
         dom = max(ktimes, key=ktimes.get)
-        alg_bytes = info["ecs_bytes"] + info["out_bytes"]            # ECS read once + RGB8 written once
+        alg_bytes = info["ecs_bytes"] + info["out_bytes"]            # SURVEY 8(d): ECS read once + picture written once
         achieved = alg_bytes / (ktimes[dom] * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel per launch, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
-        # gfx950 correction + WRITE_SIZE, both KiB); only valid for the workload it was collected on
-        traffic = None
+        # HBM traffic of the dominant kernel per launch and the VALU issue fraction, from the committed rocprofv3 PMC passes
+        # (profiles/<tag>_counters.json, written by tools/make_profile.py); only valid for the workload they were collected on
+        traffic, valu_issue_frac, prof_src = None, None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_onepass_cfg3_traffic.json")))
-            if args.workload == "cfg3" and args.images == 1024:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_cfg3_counters.json")))
+            if args.workload == tj.get("workload_key") and args.images == 1024:
+                prof_src = tj.get("source")
                 for k, v in tj["per_kernel"].items():
                     if dom in k:
-                        traffic = int((2 * (v.get("fetch_kib_raw") or 0) + (v.get("write_kib") or 0)) * 1024)
+                        traffic = v.get("traffic_bytes")
+                        valu_issue_frac = v.get("valu_issue_frac")
         except Exception:
-            traffic = None
+            pass
         line = {
-            "metric": "MPixels/sec JPEG->RGB (bit-exact BMP)", "value": round(value, 2), "unit": "MPix/s",
+            "metric": "MPixels/sec JPEG->RGB (bit-exact BMP)", "value": main_rates["value"], "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": main_rates["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16/int32 (integer IDCT), u8 out", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {label}", "images_per_gpu": info["n_images"],
-                       "pixels_per_gpu": pixels, "ecs_bytes_per_gpu": info["ecs_bytes"],
-                       "huffman_lanes": info["n_subsequences"], "exact_kernel_images": info["n_sequential"] + info["n_fallback"],
-                       "hip_graph": not args.no_graph, "batches_in_flight": nfl,
-                       "sync": {k: info[k] for k in ("n_huff_workgroups", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes")}},
+            "config": {"workload": f"{args.workload}: {R['label']}", "out_format": args.out_format,
+                       "images_per_gpu": info["n_images"], "pixels_per_gpu": pixels, "ecs_bytes_per_gpu": info["ecs_bytes"],
+                       "bytes_per_pixel": main_rates["bytes_per_pixel"], "table_sets": info["n_table_sets"],
+                       "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
+                       "exact_kernel_images": main_rates["exact_kernel_images"],
+                       "hip_graph": not args.no_graph, "batches_in_flight": nfl, "host_nproc": os.cpu_count(),
+                       "sync": dict({k: info[k] for k in ("n_huff_workgroups", "n_huff_waves", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes")},
+                                    lane_passes_per_lane=round(2.0 + info["sync_lane_passes"] / max(1, info["n_subsequences"]), 3),
+                                    note="lane_passes_per_lane = speculative pass + re-sync passes + write pass, per lane (work); a wave's "
+                                         "re-sync round lasts as long as its slowest lane")},
+            "ecs_GBps": main_rates["ecs_GBps"], "huffman_symbols_per_s": main_rates["huffman_symbols_per_s"],
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_issue_frac": valu_issue_frac,
+                         "counters_from": prof_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(ktimes[dom], 4)},
             "kernels_ms": {k: round(v, 4) for k, v in ktimes.items()},
-            "kernel_pipeline_ms": round(ktotal, 4),
-            "host_ms": {"generate": round(t_gen * 1e3, 1), "scan": round(t_scan * 1e3, 1), "upload": round(t_up * 1e3, 1)},
+            "kernel_pipeline_ms": round(R["ktotal"], 4),
+            "host_ms": R["host_ms"],
         }
-        if dt_serial is not None:
-            line["one_batch_in_flight"] = {"value": round(world * pixels * args.steps / dt_serial / 1e6, 2), "unit": "MPix/s",
-                                           "ms_per_step": round(dt_serial / args.steps * 1e3, 4),
-                                           "note": "rank 0's clock, steps strictly one after the other on one stream"}
-        if verify is not None:
-            line["verified_against_oracle"] = bool(verify)
+        if "one_batch_in_flight" in main_rates:
+            line["one_batch_in_flight"] = dict(main_rates["one_batch_in_flight"],
+                                               note="rank 0's clock, steps strictly one after the other on one stream")
+        if variants:
+            line["variants"] = variants
+        if R.get("verify") is not None:
+            line["verified_against_oracle"] = bool(R["verify"])
+        jpegs = R["jpegs"]
         if world == 1 and args.e2e_batches > 0:
             # PCIe-inclusive rate: host scan + H2D + kernels + D2H, all overlapped by libpjdpipe (3 GPU slots)
             pipe_jpegs = jpegs * args.e2e_batches
@@ -292,10 +359,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(jpegs)
         print(json.dumps(line))
-    for b in batches:
-        b.destroy()
-    for c in ctxs:
-        c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -46,13 +46,23 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.host.resize(n);
     P.qtab.assign((size_t)n * 3 * 64, 0);
 
-    // Subsequence size.  The self-synchronisation distance of a 4:2:0 stream is ~160 B on average
-    // with 5 % above 512 B (bit position, zigzag slot AND the 6-unit MCU phase must all match), so
-    // lanes should be several times that long; but a small batch needs enough lanes to fill 256 CUs.
+    // Subsequence size.  A decoder started at a wrong position falls into step with the true one only when bit position,
+    // zigzag slot AND the phase inside the MCU all agree; measured, that takes about two MCUs' worth of stream on average
+    // with a long tail (4:2:0: ~160 B at 80 B per MCU, several times that for dense high-quality streams).  A lane should
+    // be several times that long -- 5.5 MCUs' worth here -- or most lanes need more than one re-sync round; but a small
+    // batch needs enough lanes to fill 256 CUs.
     {
-        uint64_t total = 0;
-        for (int i = 0; i < n; i++) total += images[i].ecs_len;
-        uint32_t sb = total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u);
+        uint64_t total = 0, mcus = 0;
+        for (int i = 0; i < n; i++) {
+            total += images[i].ecs_len;
+            const uint32_t hs = images[i].h_samp ? images[i].h_samp : 1, vs = images[i].v_samp ? images[i].v_samp : 1;
+            mcus += (uint64_t)((images[i].width + 8 * hs - 1) / (8 * hs)) * ((images[i].height + 8 * vs - 1) / (8 * vs));
+        }
+        const uint32_t by_total = total >= (64u << 20) ? 1024u : (total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u));
+        uint64_t by_density = mcus ? (total * 11 / 2 / mcus + 63) / 64 * 64 : 512;
+        if (by_density < PJD_SUB_BYTES_MIN) by_density = PJD_SUB_BYTES_MIN;
+        if (by_density > PJD_SUB_BYTES_MAX) by_density = PJD_SUB_BYTES_MAX;
+        uint32_t sb = by_total < by_density ? by_total : (uint32_t)by_density;
         if (sub_bytes_override) {
             if (sub_bytes_override < PJD_SUB_BYTES_MIN || sub_bytes_override > PJD_SUB_BYTES_MAX || (sub_bytes_override & 63)) {
                 err = "sub_bytes override must be a multiple of 64 in [128, 1024]";

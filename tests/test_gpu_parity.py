@@ -273,6 +273,23 @@ def test_config5_tile_444_restart_rows_matches_oracle(ctx, port):
     assert np.array_equal(outs[0], want["rgb"])
 
 
+def test_dense_optimised_set_matches_oracle(ctx, port):
+    """The default benchmark set (ImageNet-class density, a Huffman table set per picture): every picture of a 64-image
+    batch against the oracle, decoded by the parallel path, BMP output."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = synth.cfg3_imagenet_like(64, seed=7, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_BMP) as b:
+        b.upload(); b.decode()
+        outs, st = b.download()
+        info = b.info()
+    assert st == [0] * 64 and info["n_sequential"] == 0 and info["n_fallback"] == 0
+    assert info["n_table_sets"] >= 60
+    for j, o in zip(jpegs, outs):
+        assert o.tobytes() == port.decode(j)["bmp"]
+
+
 def test_config3_batch_properties(ctx, port):
     """BASELINE config 3 at full size (1024 images): per-image results equal single-image decodes
     (batch independence), decoding twice is idempotent, a sample equals the oracle."""

@@ -49,6 +49,14 @@ def test_port_matches_ref_on_synth(port, ref, tmp_path):
         assert rc == 0 and out == ""
         o = port.decode(data)
         assert o["bmp"] == (tmp_path / f"s{i}.bmp").read_bytes()
+    # the dense set's pictures: more detail, per-picture optimised Huffman tables
+    for i, (w, h, q) in enumerate([(333, 200, 97), (96, 160, 88)]):
+        data = synth.make(w, h, 200 + i, q, synth.SUB_420, 0, synth.DENSE_DETAIL, True)
+        jp = tmp_path / f"d{i}.jpg"
+        jp.write_bytes(data)
+        rc, out = ref.run_cli(str(jp), str(tmp_path / f"d{i}.bmp"))
+        assert rc == 0 and out == ""
+        assert port.decode(data)["bmp"] == (tmp_path / f"d{i}.bmp").read_bytes()
 
 
 def test_imagenet_like_specs_are_deterministic():
@@ -59,3 +67,21 @@ def test_imagenet_like_specs_are_deterministic():
     d1 = synth.make(*a[0][:3], a[0][3])
     d2 = synth.make(*a[0][:3], a[0][3])
     assert hashlib.sha256(d1).digest() == hashlib.sha256(d2).digest()
+
+
+def test_dense_set_density_and_optimised_tables():
+    """The default benchmark set: ImageNet-class density (>= 0.55 B/px) with four distinct Huffman tables per picture."""
+    import pjd_amd
+    import synth
+    jp = synth.cfg3_imagenet_like(24, seed=3, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    px = by = 0
+    sets = set()
+    for j in jp:
+        s = pjd_amd.Scanned(j)
+        assert s.valid
+        d = s.desc
+        px += int(d.width) * int(d.height)
+        by += int(d.ecs_len)
+        sets.add(bytes(d.dc[0].symbols[:12]) + bytes(d.ac[0].offsets) + bytes(d.ac[1].offsets))
+    assert by / px >= 0.55, by / px
+    assert len(sets) >= 20          # per-picture tables, not one shared set

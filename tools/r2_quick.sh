@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout -k 10 300 python tools/gpu_probe.py > gpurun_out/probe.log 2>&1; echo "probe rc=$?"; tail -1 gpurun_out/probe.log; grep -c "^ok" gpurun_out/probe.log; grep FAIL gpurun_out/probe.log | head
 for sb in ${SBS:-0}; do
-  PJD_SUB_BYTES=$sb PJD_DEBUG_STATS=1 timeout -k 10 120 python bench.py --in-flight 1 --e2e-batches 0 --no-cpu-baseline --steps 10 --verify > gpurun_out/q_$sb.log 2> gpurun_out/q_$sb.err
+  PJD_SUB_BYTES=$sb PJD_DEBUG_STATS=1 timeout -k 10 120 python bench.py --in-flight 1 --e2e-batches 0 --no-cpu-baseline --steps 10 --verify --no-variants ${BENCH_ARGS:-} > gpurun_out/q_$sb.log 2> gpurun_out/q_$sb.err
   echo "bench sb=$sb rc=$?"
   python3 -c "
 import json,sys

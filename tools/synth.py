@@ -83,14 +83,19 @@ def imagenet_like_specs(n, seed=3):
     return specs
 
 
-DENSE_DETAIL = 2.2      # calibrated in tests/test_synth.py: mean density of the cfg3 set >= 0.55 B/px
+DENSE_DETAIL = 2.2      # with QUALITY_SHIFT: mean density of the cfg3 set ~0.58 B/px (tests/test_synth.py checks >= 0.55)
 
 
-def cfg3_imagenet_like(n=1024, seed=3, threads=None, detail=1.0, optimize=False, extra=()):
+QUALITY_SHIFT = {75: 88, 85: 92, 90: 95, 95: 97}   # the denser set: higher qualities, as ImageNet originals have
+
+
+def cfg3_imagenet_like(n=1024, seed=3, threads=None, detail=1.0, optimize=False, extra=(), quality_shift=False):
     """n mixed-size 4:2:0 JPEGs.  `extra`: RGB arrays re-encoded (4:2:0, q90) in place of the first pictures of the set --
-    the bench puts the bundled ImageNet sample there."""
+    the bench puts the bundled ImageNet sample there.  detail=DENSE_DETAIL with quality_shift gives ~0.58 B/px."""
     lib()
     specs = imagenet_like_specs(n, seed)
+    if quality_shift:
+        specs = [(w, h, sd, QUALITY_SHIFT[q]) for (w, h, sd, q) in specs]
     threads = threads or min(16, os.cpu_count() or 4)
     with ThreadPoolExecutor(threads) as ex:      # ctypes drops the GIL inside the C call
         out = list(ex.map(lambda s: make(s[0], s[1], s[2], s[3], SUB_420, 0, detail, optimize), specs))
