@@ -24,7 +24,11 @@ Workloads (synthetic and seeded -- there is no dataset on the box; tools/synth.p
     cfg3lite the round-1 set itself as the main workload
     cfg2     one 3840x2160 4:2:0 q85 JPEG without restart markers
     cfg2rst  the same picture with one restart interval per MCU row
-    cfg5     one 8192x8192 4:4:4 JPEG, one restart interval per MCU row (size via --tile)
+    cfg5     one 8192x8192 4:4:4 JPEG, one restart interval per MCU row (size via --tile); every rank decodes its own
+    cfg5split  BASELINE config 5 as stated: ONE picture (--tile, default 8192; 16384 is the config's size) scanned on rank 0,
+             descriptor broadcast + entropy-coded bytes scattered over the process group (nccl = RCCL over xGMI), every
+             rank decodes only its restart-segment range; value = the picture's pixels / slowest rank (strong scaling).
+             With --gpus 1 it is the plain cfg5 measurement.
 """
 import argparse
 import json
@@ -67,7 +71,7 @@ def make_workload(name, n_images, seed, tile, device=0):
         return [synth.cfg2_single_4k(seed=seed)], "one 3840x2160 4:2:0 q85 JPEG, no restart markers"
     if name == "cfg2rst":
         return [synth.cfg2_single_4k(seed=seed, restart_rows=True)], "one 3840x2160 4:2:0 q85 JPEG, restart interval = one MCU row"
-    if name == "cfg5":
+    if name in ("cfg5", "cfg5split"):
         return [synth.cfg5_tile(tile, seed=seed)], f"one {tile}x{tile} 4:4:4 q85 JPEG, restart interval = one MCU row"
     raise SystemExit(f"unknown workload {name}")
 
@@ -200,13 +204,29 @@ def main():
     def measure(workload, steps, warmup, full):
         """Generate `workload`, make `nfl` resident batches, time `steps` steps.  full: also the serialised run and the
         per-kernel HIP-event timings."""
+        split = workload == "cfg5split" and world > 1
         t_gen = time.perf_counter()
-        jpegs, label = make_workload(workload, args.images, 3 + rank, args.tile, local_rank)
+        if split and rank != 0:
+            jpegs, label = [], ""
+        else:
+            jpegs, label = make_workload(workload, args.images, 3 + (0 if split else rank), args.tile, local_rank)
         t_gen = time.perf_counter() - t_gen
         t_scan = time.perf_counter()
         scanned = [pjd_amd.Scanned(j) for j in jpegs]
         t_scan = time.perf_counter() - t_scan
         assert all(s.valid for s in scanned)
+        t_dist, keep = 0.0, None
+        if split:
+            # rank 0 scanned the file: one broadcast of the descriptor, every rank receives its slice of the bitstream
+            from pjd_amd import parallel
+            t_dist = time.perf_counter()
+            d, keep, blob_bytes = parallel.distribute_image(scanned[0] if rank == 0 else None, src=0, device=torch.device("cuda", local_rank))
+            t_dist = time.perf_counter() - t_dist
+            descs = [d] if d is not None else []
+            label = label or f"one {args.tile}x{args.tile} 4:4:4 q85 JPEG, restart interval = one MCU row"
+            label += f"; split by restart segment over {world} ranks (descriptor blob {blob_bytes} B broadcast)"
+        else:
+            descs = [s.desc for s in scanned]
         if workload == "cfg2rst":
             # 4:2:0 + DRI: the reference's own restart rule garbles such files (SURVEY 0.7); decode per ITU-T.81
             for s in scanned:
@@ -214,7 +234,7 @@ def main():
         # One context = one HIP stream.  `--in-flight` identical batches are resident; step i decodes batch i % in_flight,
         # so consecutive steps overlap (the slow tail of one step's entropy decode runs beside the next step's bulk).
         ctxs = [pjd_amd.Context(local_rank) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing
-        batches = [c.batch([s.desc for s in scanned], out_fmt) for c in ctxs]
+        batches = [c.batch(descs, out_fmt) for c in ctxs]
         batch = batches[0]
         t_up = time.perf_counter()
         batch.upload()
@@ -234,8 +254,10 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        r = {"jpegs": jpegs, "label": label, "dt": dt, "steps": steps, "host_ms": {"generate": round(t_gen * 1e3, 1),
+        r = {"jpegs": jpegs, "label": label, "dt": dt, "steps": steps, "split": split, "host_ms": {"generate": round(t_gen * 1e3, 1),
              "scan": round(t_scan * 1e3, 1), "upload": round(t_up * 1e3, 1)}}
+        if split:
+            r["host_ms"]["distribute"] = round(t_dist * 1e3, 1)
         # the same K steps strictly one after the other (reported beside `value`, never instead of it)
         if nfl > 1:
             barrier()
@@ -273,14 +295,15 @@ def main():
     def rates(r):
         """Throughput figures of one measurement (whole job: all ranks)."""
         info, dt, k = r["info"], r["dt"], r["steps"]
-        o = {"value": round(world * info["pixels"] * k / dt / 1e6, 2), "unit": "MPix/s", "ms_per_step": round(dt / k * 1e3, 4),
+        mult = 1 if r.get("split") else world        # a split picture is counted once (every rank's plan names the whole picture)
+        o = {"value": round(mult * info["pixels"] * k / dt / 1e6, 2), "unit": "MPix/s", "ms_per_step": round(dt / k * 1e3, 4),
              "ecs_GBps": round(world * info["ecs_bytes"] * k / dt / 1e9, 2),
              "huffman_symbols_per_s": round(world * info["n_entries"] * k / dt, 0),
              "bytes_per_pixel": round(info["ecs_bytes"] / info["pixels"], 3), "table_sets": info["n_table_sets"],
              "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
              "exact_kernel_images": info["n_sequential"] + info["n_fallback"]}
         if "dt_serial" in r:
-            o["one_batch_in_flight"] = {"value": round(world * info["pixels"] * k / r["dt_serial"] / 1e6, 2), "unit": "MPix/s",
+            o["one_batch_in_flight"] = {"value": round(mult * info["pixels"] * k / r["dt_serial"] / 1e6, 2), "unit": "MPix/s",
                                         "ms_per_step": round(r["dt_serial"] / k * 1e3, 4)}
         return o
 
@@ -314,7 +337,7 @@ def main():
         line = {
             "metric": "MPixels/sec JPEG->RGB (bit-exact BMP)", "value": main_rates["value"], "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_rates["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": main_rates["ms_per_step"], "higher_is_better": True, "scaling": "strong" if R.get("split") else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (integer IDCT), u8 out", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {R['label']}", "out_format": args.out_format,
                        "images_per_gpu": info["n_images"], "pixels_per_gpu": pixels, "ecs_bytes_per_gpu": info["ecs_bytes"],

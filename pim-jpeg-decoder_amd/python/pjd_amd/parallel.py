@@ -108,6 +108,9 @@ def shard_descriptor(desc: ImageDesc, seg_offsets: np.ndarray, ecs_slice: np.nda
     The C ABI takes segment offsets relative to the ecs pointer it is given, so a rank that holds only
     its slice passes rebased offsets for its own range and marks the rest as empty."""
     f, c = segment_range(len(seg_offsets), rank, world)
+    if c == 0:
+        # more ranks than restart segments: this rank has nothing to decode (shard_n_segs == 0 would mean "all")
+        return None, None
     d = ImageDesc()
     C.memmove(C.byref(d), C.byref(desc), _BLOB_HDR)
     segs = np.zeros(len(seg_offsets), np.uint64)
@@ -122,3 +125,22 @@ def shard_descriptor(desc: ImageDesc, seg_offsets: np.ndarray, ecs_slice: np.nda
     d.n_segments = len(segs)
     d.shard_first_seg, d.shard_n_segs = f, c
     return d, keep
+
+
+def distribute_image(scanned, src=0, device=None):
+    """The whole exchange of the split-image case (BASELINE config 5): the rank that scanned the file broadcasts the
+    descriptor (one collective) and sends every rank the entropy-coded bytes of its restart-segment range; each rank gets
+    the ImageDesc of its shard.  `scanned`: a pjd_amd.Scanned on rank `src`, None elsewhere.
+    -> (desc or None if this rank has no segments, keep-alive tuple, bytes of the descriptor blob)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank == src:
+        blob = pack_descriptor(scanned.desc, scanned.seg_offsets())
+        ecs, n = scanned.ecs(), int(scanned.desc.ecs_len)
+    else:
+        blob, ecs, n = None, None, 0
+    blob = broadcast_descriptor(blob, src=src, device=device)
+    desc, segs = unpack_descriptor(blob)
+    sl, lo = scatter_ecs(ecs, segs, n if rank == src else int(desc.ecs_len), src=src, device=device)
+    d, keep = shard_descriptor(desc, segs, sl, lo, rank, world)
+    return d, keep, len(blob)

@@ -273,6 +273,45 @@ def test_config5_tile_444_restart_rows_matches_oracle(ctx, port):
     assert np.array_equal(outs[0], want["rgb"])
 
 
+def test_config5_full_size_shards_and_oracle_band(ctx, port):
+    """BASELINE config 5 at its full size on one GPU: a 16384x16384 4:4:4 picture with a restart interval per MCU row.
+    (a) the unsharded decode and the eight shard decodes a node's ranks would do (segment_range(.., r, 8), each from only
+    its slice of the bitstream) give the same bytes; (b) a band of MCU rows equals the oracle's decode of the same rows
+    encoded on their own (restart intervals make MCU rows independent, so the band's entropy-coded data is the same)."""
+    import pjd_amd
+    from pjd_amd import parallel
+    synth = _synth()
+    size, world = 16384, 8
+    rgb = synth.picture(size, size, 5)
+    data = synth.encode(rgb, 85, synth.SUB_444, size // 8)
+    s = pjd_amd.Scanned(data)
+    assert s.valid and s.desc.n_segments == size // 8
+    segs, ecs = s.seg_offsets(), s.ecs()
+    with ctx.batch([s.desc]) as b:
+        b.upload(); b.decode()
+        outs, st = b.download()
+        info = b.info()
+    assert st == [0] and info["n_sequential"] == 0 and info["n_fallback"] == 0
+    full = outs[0].reshape(size, size, 3)
+    # (b) the oracle on a band
+    y0, rows = 8192 + 64, 64
+    band = port.decode(synth.encode(rgb[y0:y0 + rows], 85, synth.SUB_444, size // 8))
+    assert band["huff_rc"] == 0
+    assert np.array_equal(full[y0:y0 + rows], band["rgb"])
+    del rgb
+    # (a) shard by shard
+    for r in range(world):
+        f, c = parallel.segment_range(len(segs), r, world)
+        lo = int(segs[f])
+        hi = int(segs[f + c]) if f + c < len(segs) else len(ecs)
+        d, keep = parallel.shard_descriptor(s.desc, segs, ecs[lo:hi], lo, r, world)
+        souts, sst = ctx.decode([d], pjd_amd.OUT_RGB8)
+        assert sst == [0]
+        got = souts[0].reshape(size, size, 3)[f * 8:(f + c) * 8]
+        assert np.array_equal(got, full[f * 8:(f + c) * 8]), r
+        del souts, got
+
+
 def test_dense_optimised_set_matches_oracle(ctx, port):
     """The default benchmark set (ImageNet-class density, a Huffman table set per picture): every picture of a 64-image
     batch against the oracle, decoded by the parallel path, BMP output."""

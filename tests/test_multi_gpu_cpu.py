@@ -31,17 +31,12 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         data = golden_bytes("rstrow_200x150_444_opt")
-        if rank == 0:
-            s = pjd_amd.Scanned(data)
-            blob = parallel.pack_descriptor(s.desc, s.seg_offsets())
-            ecs, n = s.ecs(), int(s.desc.ecs_len)
-            segs0 = s.seg_offsets()
-        else:
-            blob, ecs, n, segs0 = None, None, 0, None
-        blob = parallel.broadcast_descriptor(blob, src=0)
-        desc, segs = parallel.unpack_descriptor(blob)
-        sl, lo = parallel.scatter_ecs(ecs, segs, desc.ecs_len if rank else n, src=0)
-        d, keep = parallel.shard_descriptor(desc, segs, sl, lo, rank, world)
+        # the code path of bench.py --workload cfg5split: rank 0 scans, one descriptor broadcast, bitstream slices scattered
+        s = pjd_amd.Scanned(data) if rank == 0 else None
+        d, keep, blob_bytes = parallel.distribute_image(s, src=0)
+        sl, segs = keep
+        desc = d
+        lo = int(pjd_amd.Scanned(data).seg_offsets()[d.shard_first_seg])
         info = pjd_amd.plan_info([d])
         ret[rank] = {"w": int(desc.width), "h": int(desc.height), "nseg": int(desc.n_segments), "first": int(d.shard_first_seg),
                      "count": int(d.shard_n_segs), "slice": len(sl), "lo": int(lo), "subs": info["n_subsequences"],
@@ -68,6 +63,27 @@ def test_two_rank_descriptor_broadcast_and_scatter():
     assert ret[0]["sha"] == hashlib.sha256(ecs[:cut].tobytes()).hexdigest()
     assert ret[1]["sha"] == hashlib.sha256(ecs[cut:].tobytes()).hexdigest()
     assert ret[0]["seq"] == 0 and ret[1]["seq"] == 0 and ret[0]["subs"] > 0 and ret[1]["subs"] > 0
+
+
+def test_more_ranks_than_segments_leaves_ranks_idle():
+    """A rank without restart segments gets no descriptor (shard_n_segs == 0 would mean "decode everything")."""
+    import pjd_amd
+    from pjd_amd import parallel
+    s = pjd_amd.Scanned(golden_bytes("rst7_gray_61x45"))
+    segs, ecs = s.seg_offsets(), s.ecs()
+    world = len(segs) + 3
+    got = 0
+    for r in range(world):
+        f, c = parallel.segment_range(len(segs), r, world)
+        lo = int(segs[f]) if c else 0
+        hi = (int(segs[f + c]) if f + c < len(segs) else len(ecs)) if c else 0
+        d, keep = parallel.shard_descriptor(s.desc, segs, ecs[lo:hi], lo, r, world)
+        if c == 0:
+            assert d is None
+        else:
+            assert d.shard_n_segs == c and pjd_amd.plan_info([d])["n_sequential"] == 0
+            got += c
+    assert got == len(segs)
 
 
 def test_lpt_and_segment_ranges():
