@@ -14,6 +14,13 @@
  *                      the H2D of one batch, the kernels of another and the D2H of a third overlap
  *     sink workers  -> hand every picture to the caller's sink (the CLI writes "<stem>.bmp")
  *
+ * Several GPUs (the reference's dpu_alloc(DPU_ALLOCATE_ALL) + one picture per DPU, src/decoder_host.cpp:225,
+ * 262-300): `devices` lists HIP ordinals; every device gets `slots` slots of its own and its own queue of
+ * batches.  Batches are dealt to devices before scanning starts, longest-processing-time first on their input
+ * bytes (pjd_pipe_assign) -- the CLI sorts inputs by size like the reference (:46-61), so consecutive batches
+ * differ a lot in cost -- and a device that runs dry takes batches from the others' queues.  No picture ever
+ * crosses from one GPU to another: the path has no exchange step.
+ *
  * Inputs keep their order inside a batch; batches complete in any order.  Error behaviour is the
  * reference's: a file the scanner rejects produces its messages and no picture; a Huffman error
  * produces the message and the partial picture (src/decoder_host.cpp:120-123,181).
@@ -38,6 +45,8 @@ extern "C" {
 typedef void (*pjd_pipe_sink)(void *user, int index, const char *name, const char *log, int status,
                               const uint8_t *data, uint64_t len);
 
+#define PJD_PIPE_MAX_DEVICES 16
+
 typedef struct pjd_pipe_opts {
     int32_t device;          /* HIP device ordinal                                             */
     int32_t out_format;      /* PJD_OUT_BMP / PJD_OUT_RGB8                                     */
@@ -47,6 +56,9 @@ typedef struct pjd_pipe_opts {
     int32_t sink_threads;    /* workers calling the sink           (0 -> 4)                    */
     pjd_pipe_sink sink;      /* may be NULL (pictures are dropped: measurement only)           */
     void *sink_user;
+    const int32_t *devices;  /* HIP ordinals to spread the batches over; NULL -> { device }    */
+    int32_t n_devices;       /* entries in `devices` (at most PJD_PIPE_MAX_DEVICES)            */
+    int32_t reserved_;
 } pjd_pipe_opts;
 
 typedef struct pjd_pipe_stats {
@@ -54,12 +66,21 @@ typedef struct pjd_pipe_stats {
     double scan_s, create_s, upload_s, exec_s, download_s, sink_s;   /* summed over workers   */
     uint64_t n_inputs, n_decoded, n_rejected, n_batches, n_batch_failures;
     uint64_t pixels, in_bytes, ecs_bytes, out_bytes;
+    uint64_t n_devices;                              /* devices that opened                    */
+    uint64_t n_stolen;                               /* batches run by another device than the one they were dealt to */
+    uint64_t device_batches[PJD_PIPE_MAX_DEVICES];   /* batches run per entry of `devices`     */
+    uint64_t device_in_bytes[PJD_PIPE_MAX_DEVICES];  /* input bytes of those batches           */
 } pjd_pipe_stats;
 
 /* Returns PJD_OK, PJD_E_NODEVICE if no slot could open the device, PJD_E_ARG.                 */
 int pjd_pipe_run_files(const char *const *paths, int n, const pjd_pipe_opts *opts, pjd_pipe_stats *stats);
 int pjd_pipe_run_memory(const uint8_t *const *data, const uint64_t *len, const char *const *names, int n,
                         const pjd_pipe_opts *opts, pjd_pipe_stats *stats);
+
+/* The dealing rule on its own (no GPU needed): item k of cost[k] goes to device_of[k] in [0, n_devices);
+ * items are taken by descending cost (ties: lower index first) and given to the least loaded device
+ * (ties: lower device first).  Returns PJD_OK or PJD_E_ARG.                                     */
+int pjd_pipe_assign(const uint64_t *cost, int n, int n_devices, int32_t *device_of);
 
 /* GPU slots (context, buffer pools, page-locked output buffer) are kept between runs; this frees them. */
 void pjd_pipe_release(void);

@@ -12,9 +12,10 @@
 // counters become per-kernel milliseconds measured with HIP events.
 //
 // Extensions (do not change the default behaviour): --device N, --batch M (images per GPU batch),
-// --pipeline [--slots S --scan-threads T --write-threads W]: the pipelined batcher of
+// --pipeline [--slots S --scan-threads T --write-threads W --devices 0,1,...]: the pipelined batcher of
 // include/pjd_pipeline.h (scan, copies, kernels and BMP writes overlap; messages are printed in input
-// order at the end instead of interleaved).
+// order at the end instead of interleaved).  --devices spreads the batches over several GPUs of the node,
+// as the reference spreads pictures over all allocated DPUs (:225); it implies --pipeline.
 #include <sys/stat.h>
 #include <time.h>
 
@@ -61,7 +62,8 @@ static void pipe_sink(void *user, int index, const char *name, const char *log, 
     }
 }
 
-static int run_pipeline(const std::vector<std::string> &files, int device, int batch_images, int slots, int scan_threads, int write_threads)
+static int run_pipeline(const std::vector<std::string> &files, const std::vector<int32_t> &devices, int batch_images, int slots, int scan_threads,
+                        int write_threads)
 {
     std::vector<const char *> paths;
     for (const std::string &f : files) paths.push_back(f.c_str());
@@ -69,7 +71,8 @@ static int run_pipeline(const std::vector<std::string> &files, int device, int b
     po.messages.resize(files.size());
     pjd_pipe_opts o;
     std::memset(&o, 0, sizeof o);
-    o.device = device; o.out_format = PJD_OUT_BMP; o.batch_images = batch_images;
+    o.device = devices[0]; o.devices = devices.data(); o.n_devices = (int32_t)devices.size();
+    o.out_format = PJD_OUT_BMP; o.batch_images = batch_images;
     o.slots = slots; o.scan_threads = scan_threads; o.sink_threads = write_threads;
     o.sink = pipe_sink; o.sink_user = &po;
     pjd_pipe_stats st;
@@ -78,7 +81,12 @@ static int run_pipeline(const std::vector<std::string> &files, int device, int b
         std::cout << "Error - no usable MI355X (gfx950) device (pjd_open returned " << rc << ")\n";
         return 2;
     }
-    std::cout << "1 MI355X device is allocated\n";
+    if (rc != PJD_OK) {
+        std::cout << "Error - Invalid arguments\n";
+        return 1;
+    }
+    if (st.n_devices == 1) std::cout << "1 MI355X device is allocated\n";
+    else std::cout << st.n_devices << " MI355X devices are allocated\n";
     for (const std::string &m : po.messages) std::cout << m;
     std::cout << "\nProfiles:\n";
     std::cout << "End-to-end execution time: " << st.wall_s << "s\n";
@@ -90,6 +98,8 @@ static int run_pipeline(const std::vector<std::string> &files, int device, int b
     std::cout << " - GPU-to-CPU transfer time: " << st.download_s << "s\n";
     std::cout << " - BMP write time: " << st.sink_s << "s\n";
     std::cout << " - Total " << st.n_batches << " calls, " << st.n_decoded << " pictures, " << st.pixels / 1e6 << " MPixels\n";
+    for (size_t d = 0; d < devices.size() && devices.size() > 1; d++)
+        std::cout << " - device " << devices[d] << ": " << st.device_batches[d] << " calls, " << st.device_in_bytes[d] / 1e6 << " MB of input\n";
     return 0;
 }
 
@@ -100,8 +110,19 @@ int main(int argc, char **argv)
     bool pipeline = false;
     int slots = 0, scan_threads = 0, write_threads = 0;
     std::vector<std::string> files;
+    std::vector<int32_t> devices;
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {
+            for (const char *p = argv[++i]; *p;) {
+                char *end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) { devices.clear(); devices.push_back(-1); break; }     // not a number: rejected below
+                devices.push_back((int32_t)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+            pipeline = true;
+        }
         else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch_images = (size_t)std::atoll(argv[++i]);
         else if (!std::strcmp(argv[i], "--pipeline")) pipeline = true;
         else if (!std::strcmp(argv[i], "--slots") && i + 1 < argc) slots = std::atoi(argv[++i]);
@@ -123,7 +144,8 @@ int main(int argc, char **argv)
     if (pipeline) {
         std::vector<std::string> ordered;
         for (const auto &p : sized) ordered.push_back(p.second);
-        return run_pipeline(ordered, device, (int)batch_images, slots, scan_threads, write_threads);
+        if (devices.empty()) devices.push_back(device);
+        return run_pipeline(ordered, devices, (int)batch_images, slots, scan_threads, write_threads);
     }
 
     pjd_ctx *ctx = nullptr;

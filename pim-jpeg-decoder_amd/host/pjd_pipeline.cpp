@@ -3,15 +3,22 @@
 // Stands where the reference has its producer thread (mcu_prepare, reference src/decoder_host.cpp:104-211),
 // its consumer thread (offloading, :213-350) and the std::queue<Batch> between them (:25-38):
 //
-//   scan workers --(batch complete)--> ready queue --> GPU slots --(pictures)--> sink queue --> sink workers
+//   scan workers --(batch complete)--> ready queue of the batch's device --> that device's GPU slots
+//                --(pictures)--> sink queue --> sink workers
 //
 // A batch is `batch_images` CONSECUTIVE inputs, so its composition does not depend on thread timing.
 // Every GPU slot owns a pjd_ctx, i.e. its own HIP stream and its own buffer pool: while one slot's
 // kernels run, another slot's bitstreams go up and a third slot's pictures come down.  Pictures leave
 // the GPU in one packed copy into page-locked memory (pjd_batch_download_packed).
+//
+// With several devices (the reference spreads pictures over all its DPUs, src/decoder_host.cpp:225,262-300) each
+// device has its own slots and its own ready queue; batches are dealt to devices up front by pjd_pipe_assign
+// (longest first onto the least loaded device, by input bytes), and a device whose queue has run dry takes
+// batches from the others once scanning is over.
 #include <sys/stat.h>
 #include <time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -45,6 +52,8 @@ struct Input {
 
 struct Job {                             // one batch: inputs [first, first + count)
     int first = 0, count = 0;
+    int dev = 0;                         // index into Pipe::devs the batch was dealt to
+    uint64_t cost = 0;                   // input bytes
     std::atomic<int> scanned{0};
 };
 
@@ -64,6 +73,14 @@ struct Queue {
     bool closed = false;
     void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(v)); } cv.notify_one(); }
     void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+    bool try_pop(T &out)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (q.empty()) return false;
+        out = std::move(q.front());
+        q.pop_front();
+        return true;
+    }
     bool pop(T &out)
     {
         std::unique_lock<std::mutex> l(m);
@@ -116,7 +133,8 @@ struct Pipe {
     std::vector<Input> in;
     std::vector<std::unique_ptr<Job>> jobs;
     std::atomic<int> next_input{0};
-    Queue<int> ready;                    // job indices whose inputs are all scanned
+    std::vector<int> devs;               // HIP ordinals in use
+    std::vector<std::unique_ptr<Queue<int>>> ready;   // per device: job indices whose inputs are all scanned
     Queue<SinkTask> sinkq;
     std::mutex stat_m, latch_m;
     std::condition_variable latch_cv;
@@ -144,7 +162,7 @@ struct Pipe {
             }
             t_scan += now_s() - t0;
             Job &j = *jobs[i / o.batch_images];
-            if (j.scanned.fetch_add(1) + 1 == j.count) ready.push(i / o.batch_images);
+            if (j.scanned.fetch_add(1) + 1 == j.count) ready[j.dev]->push(i / o.batch_images);
         }
         std::lock_guard<std::mutex> l(stat_m);
         st.scan_s += t_scan;
@@ -158,16 +176,25 @@ struct Pipe {
         sinkq.push(SinkTask{index, status, data, len, latch});
     }
 
-    void slot_worker()
+    // next batch for a slot of device `d`: its own queue first; when that is closed and empty, the others'
+    bool next_job(int d, int &j, bool &stolen)
     {
-        SlotRes res = take_slot(o.device);
+        stolen = false;
+        if (ready[d]->pop(j)) return true;
+        for (size_t k = 1; k < ready.size(); k++)
+            if (ready[(d + k) % ready.size()]->try_pop(j)) { stolen = true; return true; }
+        return false;
+    }
+
+    void slot_worker(int d, SlotRes res)
+    {
         pjd_ctx *ctx = res.ctx;
-        if (ctx) slots_open.fetch_add(1);
         uint8_t *&pinned = res.pinned;
         uint64_t &pinned_cap = res.pinned_cap;
         std::atomic<int> latch{0};
         int j;
-        while (ready.pop(j)) {
+        bool stolen;
+        while (next_job(d, j, stolen)) {
             Job &job = *jobs[j];
             std::vector<int> idx;                          // inputs of this batch the scanner accepted
             std::vector<pjd_image_desc> descs;
@@ -227,6 +254,7 @@ struct Pipe {
             st.n_batches++; st.n_batch_failures += failed ? 1 : 0;
             st.n_decoded += decoded; st.n_rejected += rejected;
             st.pixels += pixels; st.ecs_bytes += ecs; st.out_bytes += outb;
+            st.device_batches[d]++; st.device_in_bytes[d] += job.cost; st.n_stolen += stolen ? 1 : 0;
         }
         park_slot(res);
     }
@@ -265,12 +293,53 @@ struct Pipe {
             jobs[k]->count = (k + 1) * o.batch_images <= n ? o.batch_images : n - k * o.batch_images;
         }
         st.n_inputs = (uint64_t)n;
+        // open the slots first: a device that does not open is left out of the deal
+        std::vector<std::vector<SlotRes>> res;
+        {
+            std::vector<int> live;
+            for (int dev : devs) {
+                std::vector<SlotRes> r;
+                for (int k = 0; k < o.slots; k++) {
+                    SlotRes s = take_slot(dev);
+                    if (!s.ctx) { park_slot(s); break; }
+                    r.push_back(s);
+                }
+                if (!r.empty()) { live.push_back(dev); res.push_back(std::move(r)); }
+            }
+            if (live.empty()) {                            // no device: one slot without a context reports every batch as failed
+                SlotRes none;
+                none.device = devs[0];
+                res.push_back(std::vector<SlotRes>(1, none));
+                live.push_back(devs[0]);
+            } else {
+                for (const std::vector<SlotRes> &r : res) slots_open.fetch_add((int)r.size());
+                st.n_devices = live.size();
+            }
+            devs = live;
+        }
+        for (size_t d = 0; d < devs.size(); d++) ready.emplace_back(new Queue<int>);
+        // deal the batches: cost = input bytes (stat for files; a file that cannot be read costs nothing)
+        {
+            std::vector<uint64_t> cost((size_t)nb, 0);
+            for (int k = 0; k < nb; k++) {
+                for (int i = jobs[k]->first; i < jobs[k]->first + jobs[k]->count; i++) {
+                    struct stat sb;
+                    if (in[i].path) cost[k] += stat(in[i].path, &sb) == 0 ? (uint64_t)sb.st_size : 0;
+                    else cost[k] += in[i].len;
+                }
+                jobs[k]->cost = cost[k];
+            }
+            std::vector<int32_t> dev_of((size_t)nb, 0);
+            if (nb > 0) pjd_pipe_assign(cost.data(), nb, (int)devs.size(), dev_of.data());
+            for (int k = 0; k < nb; k++) jobs[k]->dev = dev_of[k];
+        }
         std::vector<std::thread> scanners, slots, sinks;
         for (int k = 0; k < o.sink_threads && o.sink; k++) sinks.emplace_back([this] { sink_worker(); });
-        for (int k = 0; k < o.slots; k++) slots.emplace_back([this] { slot_worker(); });
+        for (size_t d = 0; d < devs.size(); d++)
+            for (const SlotRes &r : res[d]) slots.emplace_back([this, d, r] { slot_worker((int)d, r); });
         for (int k = 0; k < o.scan_threads; k++) scanners.emplace_back([this] { scan_worker(); });
         for (std::thread &t : scanners) t.join();
-        ready.close();                                     // every job has been pushed by now
+        for (auto &q : ready) q->close();                  // every job has been pushed by now
         for (std::thread &t : slots) t.join();
         sinkq.close();
         for (std::thread &t : sinks) t.join();
@@ -288,6 +357,16 @@ int run_pipe(Pipe &p, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
     if (p.o.slots <= 0) p.o.slots = 3;
     if (p.o.sink_threads <= 0) p.o.sink_threads = 4;
     if (p.o.out_format != PJD_OUT_BMP && p.o.out_format != PJD_OUT_RGB8) return PJD_E_ARG;
+    if (p.o.devices && p.o.n_devices > 0) {
+        if (p.o.n_devices > PJD_PIPE_MAX_DEVICES) return PJD_E_ARG;
+        for (int k = 0; k < p.o.n_devices; k++) {
+            const int d = p.o.devices[k];
+            if (d < 0 || std::find(p.devs.begin(), p.devs.end(), d) != p.devs.end()) return PJD_E_ARG;   // negative / listed twice
+            p.devs.push_back(d);
+        }
+    } else {
+        p.devs.push_back(p.o.device);
+    }
     const int rc = p.run();
     if (stats) *stats = p.st;
     return rc;
@@ -296,6 +375,21 @@ int run_pipe(Pipe &p, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
 }  // namespace
 
 extern "C" {
+
+int pjd_pipe_assign(const uint64_t *cost, int n, int n_devices, int32_t *device_of)
+{
+    if (n < 0 || n_devices <= 0 || (n > 0 && (!cost || !device_of))) return PJD_E_ARG;
+    std::vector<int> order((size_t)n);
+    for (int k = 0; k < n; k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::vector<uint64_t> load((size_t)n_devices, 0);
+    for (int k : order) {
+        const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());   // first of the least loaded
+        device_of[k] = d;
+        load[d] += cost[k] ? cost[k] : 1;                  // empty batches still take a turn
+    }
+    return PJD_OK;
+}
 
 void pjd_pipe_release(void)
 {

@@ -335,7 +335,11 @@ SINK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int
 class PipeOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("out_format", C.c_int32), ("batch_images", C.c_int32),
                 ("scan_threads", C.c_int32), ("slots", C.c_int32), ("sink_threads", C.c_int32),
-                ("sink", SINK_FN), ("sink_user", C.c_void_p)]
+                ("sink", SINK_FN), ("sink_user", C.c_void_p),
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_int32), ("reserved_", C.c_int32)]
+
+
+PIPE_MAX_DEVICES = 16
 
 
 class PipeStats(C.Structure):
@@ -343,10 +347,12 @@ class PipeStats(C.Structure):
                 ("exec_s", C.c_double), ("download_s", C.c_double), ("sink_s", C.c_double),
                 ("n_inputs", C.c_uint64), ("n_decoded", C.c_uint64), ("n_rejected", C.c_uint64),
                 ("n_batches", C.c_uint64), ("n_batch_failures", C.c_uint64),
-                ("pixels", C.c_uint64), ("in_bytes", C.c_uint64), ("ecs_bytes", C.c_uint64), ("out_bytes", C.c_uint64)]
+                ("pixels", C.c_uint64), ("in_bytes", C.c_uint64), ("ecs_bytes", C.c_uint64), ("out_bytes", C.c_uint64),
+                ("n_devices", C.c_uint64), ("n_stolen", C.c_uint64),
+                ("device_batches", C.c_uint64 * PIPE_MAX_DEVICES), ("device_in_bytes", C.c_uint64 * PIPE_MAX_DEVICES)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("device_") else getattr(self, k)) for k, _ in self._fields_}
 
 
 _pipe = None
@@ -365,6 +371,8 @@ def pipe_lib():
         L.pjd_pipe_run_memory.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int,
                                           C.POINTER(PipeOpts), C.POINTER(PipeStats)]
         L.pjd_pipe_release.restype = None
+        L.pjd_pipe_assign.restype = C.c_int
+        L.pjd_pipe_assign.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_int32)]
         _pipe = L
     return _pipe
 
@@ -374,9 +382,22 @@ def pipe_release():
         _pipe.pjd_pipe_release()
 
 
+def pipe_assign(costs, n_devices):
+    """The batcher's dealing rule (pjd_pipe_assign): device index per item, longest first onto the least loaded."""
+    L = pipe_lib()
+    n = len(costs)
+    c = (C.c_uint64 * max(n, 1))(*[int(x) for x in costs])
+    out = (C.c_int32 * max(n, 1))()
+    rc = L.pjd_pipe_assign(c, n, n_devices, out)
+    if rc != 0:
+        raise PjdError(f"pjd_pipe_assign failed ({rc})")
+    return [int(out[k]) for k in range(n)]
+
+
 def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_images=1024, scan_threads=0, slots=0,
-             sink_threads=0, sink=None, device=0):
+             sink_threads=0, sink=None, device=0, devices=None):
     """Run the pipelined batcher over in-memory JPEGs (`jpegs`: list of bytes) or files (`paths`).
+    `devices`: HIP ordinals to spread the batches over (default: `device` alone).
 
     `sink(index, name, log, status, data)` is called from worker threads with `data` a numpy copy of the
     picture (or None).  Returns the statistics as a dict."""
@@ -384,6 +405,9 @@ def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_image
     o = PipeOpts()
     o.device, o.out_format, o.batch_images = device, out_format, batch_images
     o.scan_threads, o.slots, o.sink_threads = scan_threads, slots, sink_threads
+    if devices is not None:
+        dv = (C.c_int32 * max(len(devices), 1))(*[int(d) for d in devices])
+        o.devices, o.n_devices = C.cast(dv, C.POINTER(C.c_int32)), len(devices)
 
     def _tramp(user, index, name, log, status, data, length):
         pic = np.ctypeslib.as_array(data, shape=(length,)).copy() if data and length else None

@@ -416,6 +416,39 @@ def test_pipeline_cli_matches_plain_cli(tmp_path):
             assert hashlib.sha256(bmp.read_bytes()).hexdigest() == ent["bmp_sha256"], n
 
 
+def test_pipeline_devices_list_of_one_equals_single_device(tmp_path):
+    """--devices 0 (the multi-device path with one device) writes what --pipeline --device 0 writes; a device
+    that does not exist is left out of the deal and the run still completes on the ones that opened."""
+    import shutil
+    import subprocess
+    import pjd_amd
+    from conftest import ROOT
+    names = [n for n in VALID[:16]]
+    outs = {}
+    for tag, extra in (("one", ["--pipeline", "--device", "0"]), ("list", ["--devices", "0"]), ("ghost", ["--devices", "0,97"])):
+        d = tmp_path / tag
+        d.mkdir()
+        for n in names:
+            shutil.copy(os.path.join(HERE, "golden", n + ".jpg"), d / (n + ".jpg"))
+        p = subprocess.run([os.path.join(ROOT, "bin", "decoder"), "--batch", "3", "--slots", "2"] + extra + [str(d / (n + ".jpg")) for n in names],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "1 MI355X device is allocated" in p.stdout
+        outs[tag] = {n: (d / (n + ".bmp")).read_bytes() for n in names}
+    assert outs["one"] == outs["list"] == outs["ghost"]
+    for n in names:
+        assert hashlib.sha256(outs["list"][n]).hexdigest() == MANIFEST[n]["bmp_sha256"], n
+    # the library entry: per-device counters add up; listing a device twice is an argument error
+    jpegs = [golden_bytes(n) for n in names]
+    st = pjd_amd.pipe_run(jpegs=jpegs, batch_images=3, slots=2, devices=[0])
+    assert st["n_devices"] == 1 and st["device_batches"][0] == st["n_batches"] == 6 and st["n_stolen"] == 0
+    assert st["device_in_bytes"][0] == sum(len(j) for j in jpegs)
+    with pytest.raises(pjd_amd.PjdError):
+        pjd_amd.pipe_run(jpegs=jpegs, devices=[0, 0])
+    p = subprocess.run([os.path.join(ROOT, "bin", "decoder"), "--devices", "zero", str(tmp_path / "one" / (names[0] + ".jpg"))], capture_output=True, text=True)
+    assert p.returncode == 1 and "Error - Invalid arguments" in p.stdout
+
+
 def test_download_packed_equals_download(ctx):
     import pjd_amd
     scanned = [_desc(n) for n in VALID[:9]]

@@ -116,6 +116,33 @@ def test_libpjdpipe_exports_every_declared_symbol():
     pjd_amd.pipe_lib()             # loads together with libpjd / libpjdhost (no compute call)
 
 
+def test_pipe_assign_deals_longest_first_to_least_loaded():
+    """The multi-device batcher's dealing rule (pjd_pipe_assign, no GPU): LPT on input bytes, deterministic,
+    within 4/3 of the best possible makespan (Graham's bound), every device used when there are enough batches."""
+    import itertools
+    import numpy as np
+    assert pjd_amd.pipe_assign([], 3) == []
+    assert pjd_amd.pipe_assign([5, 5, 5], 1) == [0, 0, 0]
+    assert pjd_amd.pipe_assign([7, 1, 1, 1, 1, 1, 1, 1], 2) == [0, 1, 1, 1, 1, 1, 1, 1]
+    assert pjd_amd.pipe_assign([3, 3, 3, 3], 4) == [0, 1, 2, 3]          # ties: lower index, lower device
+    assert pjd_amd.pipe_assign([0, 0, 0, 0], 2) == [0, 1, 0, 1]          # empty batches still alternate
+    # size-sorted inputs in consecutive batches (what the CLI produces): ascending costs
+    rng = np.random.default_rng(5)
+    for n_dev, n in ((2, 9), (4, 10), (8, 40), (3, 7)):
+        cost = np.sort(rng.integers(1, 10 ** 9, n)).tolist()
+        dev = pjd_amd.pipe_assign(cost, n_dev)
+        assert dev == pjd_amd.pipe_assign(cost, n_dev)
+        load = [sum(c for c, d in zip(cost, dev) if d == k) for k in range(n_dev)]
+        assert all(load), load
+        if n <= 10:        # brute force the optimum
+            best = min(max(sum(c for c, d in zip(cost, a) if d == k) for k in range(n_dev)) for a in itertools.product(range(n_dev), repeat=n))
+            assert max(load) <= best * (4 / 3 - 1 / (3 * n_dev)) + 1
+        else:
+            assert max(load) <= max(sum(cost) / n_dev, max(cost)) * 4 / 3
+    with pytest.raises(pjd_amd.PjdError):
+        pjd_amd.pipe_assign([1], 0)
+
+
 def test_plan_routes_odd_huffman_tables_to_exact_kernel():
     """Planner only (no GPU): tables with more long-code prefixes than the LDS budget, or not a prefix code at all."""
     for name in ("huff_longtail_96x64_444", "huff_oversub_96x64_444"):
