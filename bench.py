@@ -367,11 +367,11 @@ def main():
             line["verified_against_oracle"] = bool(R["verify"])
         jpegs = R["jpegs"]
         if world == 1 and args.e2e_batches > 0:
-            # PCIe-inclusive rate: host scan + H2D + kernels + D2H, all overlapped by libpjdpipe (3 GPU slots)
+            # PCIe-inclusive rate: host scan + H2D + kernels + D2H, all overlapped by libpjdpipe (4 GPU slots)
             pipe_jpegs = jpegs * args.e2e_batches
             # warm-up: every slot allocates its HBM pool and page-locks its output buffer once
-            pjd_amd.pipe_run(jpegs=jpegs * 6, batch_images=len(jpegs), scan_threads=6, slots=3, sink=None, device=local_rank)
-            ps = pjd_amd.pipe_run(jpegs=pipe_jpegs, batch_images=len(jpegs), scan_threads=6, slots=3, sink=None, device=local_rank)
+            pjd_amd.pipe_run(jpegs=jpegs * 8, batch_images=len(jpegs), scan_threads=8, slots=4, sink=None, device=local_rank)
+            ps = pjd_amd.pipe_run(jpegs=pipe_jpegs, batch_images=len(jpegs), scan_threads=8, slots=4, sink=None, device=local_rank)
             pjd_amd.pipe_release()
             line["pcie_inclusive"] = {
                 "value": round(ps["pixels"] / ps["wall_s"] / 1e6, 2), "unit": "MPix/s", "out_format": "bmp",

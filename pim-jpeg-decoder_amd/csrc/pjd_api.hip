@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -123,8 +124,10 @@ struct pjd_batch {
     int32_t *d_status_init = nullptr;
     uint64_t *d_opstate = nullptr;       // wave_gen + wave_desc + ticket
     size_t opstate_bytes = 0;
-    uint8_t *h_ecs = nullptr;            // pinned staging
+    uint8_t *d_in = nullptr, *h_in = nullptr;   // the input blob (work lists + bitstreams) in HBM / page-locked memory
+    size_t in_bytes = 0;
     int32_t *h_status = nullptr;         // pinned
+    unsigned long long *h_stats = nullptr;   // pinned, 16 words
     std::vector<uint32_t> seq_list;      // what d_seq_list holds
     std::vector<PoolBlock> dev_blocks, pin_blocks;   // everything this batch took from the context's pools
     uint64_t device_bytes = 0;
@@ -222,21 +225,47 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     PjdPlan &P = b->plan;
     hipSetDevice(ctx->device);
 
-    // pinned staging for the packed bitstreams; filled now so the caller's buffers can go away
+    // One input blob per batch: the work lists and tables, then the packed bitstreams.  It is assembled in page-locked
+    // memory now (the caller's buffers can go away) and goes up in ONE copy: every separate copy of a pageable vector is
+    // staged by the runtime and waits its turn behind other streams' transfers on the copy engine (profiles/r02_pcie.md).
     rc = PJD_OK;
     auto fail = [&](int code) { pjd_batch_destroy(b); return code; };
-    if (pool_pin_alloc(ctx, (void **)&b->h_ecs, P.ecs_buf_bytes, b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
+    b->seq_list = P.seq_images;
+    std::vector<uint64_t> seq_base;
+    std::vector<int32_t> st0(P.images.size(), 0);
+    for (uint32_t i : b->seq_list) { st0[i] = PJD_STW_NEEDS_EXACT; seq_base.push_back(P.images[i].dense_base); }
+    struct Part { const void *src; size_t bytes, off; };
+    std::vector<Part> parts;
+    size_t in_bytes = 0;
+    auto part = [&](const auto &vec, size_t min_count) {
+        using T = std::remove_cv_t<std::remove_reference_t<decltype(vec[0])>>;
+        const size_t off = in_bytes;
+        parts.push_back({vec.data(), vec.size() * sizeof(T), off});
+        in_bytes = (off + std::max(vec.size(), std::max(min_count, (size_t)1)) * sizeof(T) + 255) & ~(size_t)255;
+        return off;
+    };
+    const size_t o_images = part(P.images, 0), o_tsets = part(P.tsets, 0), o_raw = part(P.tables, 0), o_qtab = part(P.qtab, 0);
+    const size_t o_segs = part(P.segs, 0), o_lanes = part(P.subs, 0), o_hwaves = part(P.hwaves, 0), o_hwgs = part(P.hwgs, 0);
+    const size_t o_iwgs = part(P.iwgs, 0), o_iwgs_dense = part(P.iwgs_dense, 0);
+    const size_t o_seq_list = part(b->seq_list, (size_t)n_images), o_seq_base = part(seq_base, (size_t)n_images), o_st0 = part(st0, (size_t)n_images);
+    const size_t o_ecs = in_bytes;
+    in_bytes += P.ecs_buf_bytes;
+    b->in_bytes = in_bytes;
+    if (pool_pin_alloc(ctx, (void **)&b->h_in, in_bytes, b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
+    for (const Part &q : parts) if (q.bytes) std::memcpy(b->h_in + q.off, q.src, q.bytes);
     {   // streams at their offsets, zeros in between (every stream is followed by >= 48 zero bytes)
+        uint8_t *h_ecs = b->h_in + o_ecs;
         uint64_t pos = 0;
         for (int i = 0; i < n_images; i++) {
             const uint64_t off = P.images[i].ecs_off, len = P.host[i].ecs_copy_len;
-            if (off > pos) std::memset(b->h_ecs + pos, 0, off - pos);
-            if (len) std::memcpy(b->h_ecs + off, P.host[i].ecs_src, len);
+            if (off > pos) std::memset(h_ecs + pos, 0, off - pos);
+            if (len) std::memcpy(h_ecs + off, P.host[i].ecs_src, len);
             pos = off + len;
         }
-        std::memset(b->h_ecs + pos, 0, P.ecs_buf_bytes - pos);
+        std::memset(h_ecs + pos, 0, P.ecs_buf_bytes - pos);
     }
     if (pool_pin_alloc(ctx, (void **)&b->h_status, sizeof(int32_t) * (n_images + 1), b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
+    if (pool_pin_alloc(ctx, (void **)&b->h_stats, 16 * sizeof(unsigned long long), b->pin_blocks) != PJD_OK) return fail(PJD_E_NOMEM);
 
     uint64_t &tot = b->device_bytes;
 #define TRY_RC(x) do { int rc_ = (x); if (rc_ != PJD_OK) return fail(rc_); } while (0)
@@ -250,20 +279,15 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
         return r;
     };
     const size_t n_hwave = P.hwaves.size();
-    TRY_RC(dev_alloc(ctx, b->d_images, P.images.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_tsets, P.tsets.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_raw, P.tables.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_qtab, P.qtab.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_segs, P.segs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_lanes, P.subs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_hwaves, n_hwave, tot));
-    TRY_RC(dev_alloc(ctx, b->d_hwgs, P.hwgs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_iwgs, P.iwgs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_iwgs_dense, P.iwgs_dense.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->d_ecs, P.ecs_buf_bytes, tot));
-    TRY_RC(dev_alloc(ctx, b->d_seq_list, (size_t)n_images, tot));
-    TRY_RC(dev_alloc(ctx, b->d_seq_base, (size_t)n_images, tot));
-    TRY_RC(dev_alloc(ctx, b->d_status_init, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->d_in, in_bytes, tot));
+    b->d_images = (PjdDevImage *)(b->d_in + o_images); b->d_tsets = (PjdDevTset *)(b->d_in + o_tsets);
+    b->d_raw = (PjdDevHuffRaw *)(b->d_in + o_raw); b->d_qtab = (uint16_t *)(b->d_in + o_qtab);
+    b->d_segs = (PjdDevSegment *)(b->d_in + o_segs); b->d_lanes = (PjdDevSub *)(b->d_in + o_lanes);
+    b->d_hwaves = (PjdDevHuffWave *)(b->d_in + o_hwaves); b->d_hwgs = (PjdDevHuffWg *)(b->d_in + o_hwgs);
+    b->d_iwgs = (PjdDevIdctWg *)(b->d_in + o_iwgs); b->d_iwgs_dense = (PjdDevIdctWg *)(b->d_in + o_iwgs_dense);
+    b->d_seq_list = (uint32_t *)(b->d_in + o_seq_list); b->d_seq_base = (uint64_t *)(b->d_in + o_seq_base);
+    b->d_status_init = (int32_t *)(b->d_in + o_st0);
+    b->d_ecs = b->d_in + o_ecs;
     TRY_RC(dev_alloc(ctx, b->dev.luts, (size_t)P.lut_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.words, (size_t)P.n_words, tot));
     TRY_RC(dev_alloc(ctx, b->dev.coef, P.dense_du * 64, tot));
@@ -305,22 +329,9 @@ int pjd_batch_upload(pjd_batch *b)
     PjdPlan &P = b->plan;
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-#define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(ctx, hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, s)); } while (0)
-    UP(b->d_images, P.images); UP(b->d_tsets, P.tsets); UP(b->d_raw, P.tables); UP(b->d_qtab, P.qtab);
-    UP(b->d_segs, P.segs); UP(b->d_lanes, P.subs); UP(b->d_hwaves, P.hwaves); UP(b->d_hwgs, P.hwgs);
-    UP(b->d_iwgs, P.iwgs); UP(b->d_iwgs_dense, P.iwgs_dense);
-    // routing: images for the exact kernel (with their place in the dense scratch), and the initial status words
-    b->seq_list = P.seq_images;
-    std::vector<uint64_t> seq_base;
-    std::vector<int32_t> st0(P.images.size(), 0);
-    for (uint32_t i : b->seq_list) { st0[i] = PJD_STW_NEEDS_EXACT; seq_base.push_back(P.images[i].dense_base); }
-    UP(b->d_seq_list, b->seq_list);
-    UP(b->d_seq_base, seq_base);
-    UP(b->d_status_init, st0);
-#undef UP
-    HIP_TRY(ctx, hipMemcpyAsync(b->d_ecs, b->h_ecs, P.ecs_buf_bytes, hipMemcpyHostToDevice, s));
+    // asynchronous: the blob is page-locked and owned by the batch
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_in, b->h_in, b->in_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(b->dev.out, 0, P.out_buf_bytes, s));   // BMP row padding stays zero
-    HIP_TRY(ctx, hipStreamSynchronize(s));                              // the vectors above are pageable
     b->uploaded = true;
     return PJD_OK;
 }
@@ -407,6 +418,17 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
 // or otherwise irregular streams).  Runs on the GPU.  A shard is re-decoded over its own segment range.
 // As in the reference (decoder_host.cpp:181 drops decode_Huffman_data's result) such an image keeps its status
 // and its partial picture; the rest of the batch is unaffected.
+// one stream per device for the packed downloads of all contexts (never destroyed: a process has few devices)
+hipStream_t download_stream(int device)
+{
+    static std::mutex m;
+    static hipStream_t streams[64] = {nullptr};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> l(m);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) streams[device] = nullptr;
+    return streams[device];
+}
+
 int settle(pjd_batch *b)
 {
     pjd_ctx *ctx = b->ctx;
@@ -545,8 +567,31 @@ int pjd_batch_download_packed(pjd_batch *b, uint8_t *host, uint64_t capacity, in
     if (capacity < P.out_buf_bytes) { ctx->err = "download_packed: buffer smaller than pjd_batch_packed_size"; return PJD_E_ARG; }
     int rc = settle(b);
     if (rc != PJD_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(host, b->dev.out, P.out_buf_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // The runtime's copy (SDMA engine) by default.  PJD_DOWNLOAD=kernel: a small copy kernel on the device's download
+    // stream storing into the mapped page-locked destination instead -- it keeps the link as busy (tools/pcie_probe.hip)
+    // and leaves the engine to the uploads, but stores waiting for the link slow concurrent decode kernels down, and
+    // the pipelined batcher measured 9.1 GPix/s with it against 11.8 with the engine (profiles/r02_pcie.md).
+    void *mapped = nullptr;
+    static const bool by_kernel = [] { const char *e = std::getenv("PJD_DOWNLOAD"); return e && !std::strcmp(e, "kernel"); }();
+    hipPointerAttribute_t attr;
+    const bool pinned = by_kernel && (P.out_buf_bytes % 16) == 0 && ((uintptr_t)host % 16) == 0 &&
+                        hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost &&
+                        hipHostGetDevicePointer(&mapped, host, 0) == hipSuccess && mapped;
+    if (by_kernel && !pinned) (void)hipGetLastError();
+    hipStream_t ds = pinned ? download_stream(ctx->device) : nullptr;
+    if (ds) {
+        // settle() has synchronised ctx->stream: the pictures are final
+        hipEvent_t done;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        pjd_launch_copy_out(ds, b->dev.out, mapped, P.out_buf_bytes);
+        hipError_t e = hipEventRecord(done, ds);
+        if (e == hipSuccess) e = hipEventSynchronize(done);
+        (void)hipEventDestroy(done);
+        HIP_TRY(ctx, e);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(host, b->dev.out, P.out_buf_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (status)
         for (size_t i = 0; i < P.images.size(); i++) status[i] = b->h_status[i] & 0xFF;
     return PJD_OK;
@@ -586,17 +631,16 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     info->sub_bytes = P.sub_bytes;
     info->n_table_sets = (uint32_t)P.tsets.size();
     info->n_huff_waves = P.hwaves.size();
-    unsigned long long st[16] = {0};
-    if (b->decoded && hipMemcpy(st, b->dev.stats, sizeof st, hipMemcpyDeviceToHost) == hipSuccess) {
+    // on the batch's own stream into page-locked memory: a plain hipMemcpy would wait for every other stream of the
+    // device (it made the slots of the pipelined batcher run in lockstep, profiles/r02_pcie.md)
+    unsigned long long *st = b->h_stats;
+    if (b->decoded && hipMemcpyAsync(st, b->dev.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(b->ctx->stream) == hipSuccess) {
         info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
         for (int r = 0; r < PJD_FLAG_REASONS && r < 8; r++) info->flag_waves[r] = st[PJD_STAT_FLAG0 + r];
+        info->n_entries = st[PJD_STAT_ENTRIES];               // entries the lanes emitted in the last decode
     }
     info->n_huff_workgroups = P.hwgs.size();
-    if (b->decoded && !P.subs.empty()) {                      // entries the lanes emitted in the last decode
-        std::vector<PjdDevLaneInfo> li(P.subs.size());
-        if (hipMemcpy(li.data(), b->dev.lane_info, li.size() * sizeof(PjdDevLaneInfo), hipMemcpyDeviceToHost) == hipSuccess)
-            for (const PjdDevLaneInfo &x : li) info->n_entries += x.n_ent;
-    }
     if (b->dev.dbg && b->decoded) {          // PJD_DEBUG_STATS: wave timeline of the last decode (units of 10 ns)
         const size_t nw = P.hwaves.size();
         std::vector<uint32_t> d(nw * 32);

@@ -63,6 +63,7 @@ enum {
     PJD_FLAG_REASONS
 };
 #define PJD_STAT_FLAG0 4
+#define PJD_STAT_ENTRIES 11  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
 
 struct PjdDevImage {
     uint32_t width, height;

@@ -13,6 +13,8 @@
 // HBM-bound integer work: coefficients are read once with 16-byte loads, tiles
 // live in LDS (row stride 144 B so that the column pass is bank-conflict free),
 // pictures are written once.
+#include <cstdlib>
+
 #include "pjd_device_common.h"
 #include "pjd_kernels.h"
 
@@ -77,6 +79,27 @@ __global__ __launch_bounds__(128) void pjd_k_dpu_payload(const uint32_t *__restr
         base[256 + pos * 64 + p] = (int16_t)g;
         base[512 + pos * 64 + p] = (int16_t)b;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed download by a kernel (opt-in, PJD_DOWNLOAD=kernel): pictures go from HBM straight into mapped
+// page-locked host memory.  Few workgroups on purpose: stores waiting for the link hold memory-system
+// queues that other kernels need (128 workgroups per copy made concurrent decode kernels 5x slower,
+// profiles/r02_pcie.md).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int pjd_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void pjd_k_copy_out(const pjd_u32x4 *__restrict__ src, pjd_u32x4 *__restrict__ dst, uint64_t n16)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+void pjd_launch_copy_out(hipStream_t s, const void *src, void *dst_mapped, uint64_t bytes)
+{
+    const uint64_t n16 = bytes / 16;       // the packed output buffer is a multiple of 256 bytes
+    static const int wgs = [] { const char *e = std::getenv("PJD_COPY_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 && v <= 4096 ? v : 16; }();
+    if (n16) hipLaunchKernelGGL(pjd_k_copy_out, dim3(wgs), dim3(256), 0, s, (const pjd_u32x4 *)src, (pjd_u32x4 *)dst_mapped, n16);
 }
 
 void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus)

@@ -732,8 +732,9 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     }
     if (dead) flag |= 1u << PJD_FLAG_TIMEOUT;
     // one status update and one counter per reason and wave
-    uint32_t wflag = flag;
-    for (int off = 1; off < 64; off <<= 1) wflag |= __shfl_xor(wflag, off);
+    uint32_t wflag = flag, went = g.valid ? li.n_ent : 0;
+    for (int off = 1; off < 64; off <<= 1) { wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off); }
+    if (l == 0) atomicAdd(B.stats + PJD_STAT_ENTRIES, (unsigned long long)went);
     if (wflag && l == 0) {
         atomicOr(reinterpret_cast<unsigned int *>(B.status + hw.image), PJD_STW_NEEDS_EXACT);
         for (int r = 0; r < PJD_FLAG_REASONS; r++)

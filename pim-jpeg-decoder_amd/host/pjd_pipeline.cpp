@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -140,6 +142,8 @@ struct Pipe {
     std::condition_variable latch_cv;
     pjd_pipe_stats st{};
     std::atomic<int> slots_open{0};
+    bool trace = std::getenv("PJD_PIPE_TRACE") != nullptr;
+    double t_run0 = 0;
 
     void add(double pjd_pipe_stats::*f, double v) { std::lock_guard<std::mutex> l(stat_m); st.*f += v; }
 
@@ -196,6 +200,7 @@ struct Pipe {
         bool stolen;
         while (next_job(d, j, stolen)) {
             Job &job = *jobs[j];
+            const double t_begin = now_s();
             std::vector<int> idx;                          // inputs of this batch the scanner accepted
             std::vector<pjd_image_desc> descs;
             uint64_t rejected = 0;
@@ -243,10 +248,16 @@ struct Pipe {
                 if (b) pjd_batch_destroy(b);
             }
             // the pinned buffer and the scan logs are referenced by the sink tasks of this batch
+            const double t_sink0 = now_s();
             {
                 std::unique_lock<std::mutex> l(latch_m);
                 latch_cv.wait(l, [&] { return latch.load() == 0; });
             }
+            if (trace)                                         // PJD_PIPE_TRACE=1: one line per batch, times in ms since the run began
+                std::fprintf(stderr, "[pjdpipe] batch %d dev %d start %.2f create %.2f upload %.2f exec %.2f download %.2f other %.2f sink-wait %.2f end %.2f%s\n",
+                             j, devs[d], (t_begin - t_run0) * 1e3, t_create * 1e3, t_up * 1e3, t_exec * 1e3, t_down * 1e3,
+                             (t_sink0 - t_begin - t_create - t_up - t_exec - t_down) * 1e3, (now_s() - t_sink0) * 1e3, (now_s() - t_run0) * 1e3,
+                             stolen ? " (stolen)" : "");
             for (int i = job.first; i < job.first + job.count; i++)
                 if (in[i].sc) { pjd_scanned_free(in[i].sc); in[i].sc = nullptr; }
             std::lock_guard<std::mutex> l(stat_m);
@@ -285,6 +296,7 @@ struct Pipe {
     int run()
     {
         const double t0 = now_s();
+        t_run0 = t0;
         const int n = (int)in.size();
         const int nb = (n + o.batch_images - 1) / o.batch_images;
         for (int k = 0; k < nb; k++) {
@@ -339,11 +351,13 @@ struct Pipe {
             for (const SlotRes &r : res[d]) slots.emplace_back([this, d, r] { slot_worker((int)d, r); });
         for (int k = 0; k < o.scan_threads; k++) scanners.emplace_back([this] { scan_worker(); });
         for (std::thread &t : scanners) t.join();
+        if (trace) std::fprintf(stderr, "[pjdpipe] scanners done %.2f\n", (now_s() - t0) * 1e3);
         for (auto &q : ready) q->close();                  // every job has been pushed by now
         for (std::thread &t : slots) t.join();
         sinkq.close();
         for (std::thread &t : sinks) t.join();
         st.wall_s = now_s() - t0;
+        if (trace) std::fprintf(stderr, "[pjdpipe] run done %.2f\n", st.wall_s * 1e3);
         return slots_open.load() > 0 || n == 0 ? PJD_OK : PJD_E_NODEVICE;
     }
 };

@@ -13,10 +13,12 @@
 //   hipcc --offload-arch=gfx950 -O2 -o bin/pcie_probe tools/pcie_probe.hip && bin/pcie_probe
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
@@ -34,8 +36,65 @@ __global__ void copy_to_host(const u32x4 *__restrict__ src, u32x4 *__restrict__ 
         __builtin_nontemporal_store(src[i], dst + i);
 }
 
+__global__ void spin_kernel(unsigned long long ticks, unsigned int *sink)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    unsigned int x = threadIdx.x;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) x = x * 1664525u + 1013904223u;
+    if (x == 0xdeadbeef) *sink = x;
+}
+
+// `pcie_probe sim THREADS ROUNDS FLAGS`: THREADS host threads, each with its own stream and buffers, loop over
+//   [memset 581 MB][H2D 110 MB][kernel busy 6 ms on every CU][D2H 581 MB], synchronising after the upload, the kernel
+// and the download like a pipeline slot does.  FLAGS is a string of letters switching parts OFF: m(emset) u(pload)
+// k(ernel); 'p' uploads from pageable memory in 14 small pieces as well.  Prints the aggregate D2H rate.
+static int simulate(int dev, int threads, int rounds, const char *flags)
+{
+    const size_t out_bytes = (size_t)581 << 20, in_bytes = (size_t)110 << 20;
+    const bool no_m = std::strchr(flags, 'm'), no_u = std::strchr(flags, 'u'), no_k = std::strchr(flags, 'k'), small = std::strchr(flags, 'p');
+    std::vector<std::thread> th;
+    std::vector<double> d2h_s((size_t)threads, 0.0), up_s((size_t)threads, 0.0);
+    std::atomic<int> bad{0};
+    const double t0 = now_s();
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            uint8_t *d = nullptr, *din = nullptr, *h = nullptr, *hin = nullptr;
+            unsigned int *sink = nullptr;
+            hipStream_t s;
+            if (hipSetDevice(dev) != hipSuccess || hipMalloc(&d, out_bytes) != hipSuccess || hipMalloc(&din, in_bytes) != hipSuccess ||
+                hipMalloc(&sink, 4) != hipSuccess || hipHostMalloc(&h, out_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(&hin, in_bytes, hipHostMallocDefault) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { bad++; return; }
+            std::memset(h, 1, out_bytes); std::memset(hin, 1, in_bytes);
+            std::vector<uint8_t> pg((size_t)2 << 20, 3);
+            for (int r = 0; r < rounds; r++) {
+                double a = now_s();
+                if (small) for (int k = 0; k < 14; k++) (void)hipMemcpyAsync(din + k * 4096, pg.data() + (size_t)k * 100000, k == 5 ? 1700000 : 60000, hipMemcpyHostToDevice, s);
+                if (!no_u) (void)hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, s);
+                if (!no_m) (void)hipMemsetAsync(d, 0, out_bytes, s);
+                (void)hipStreamSynchronize(s);
+                up_s[t] += now_s() - a;
+                if (!no_k) { spin_kernel<<<1024, 256, 0, s>>>(600000ull, sink); (void)hipStreamSynchronize(s); }
+                a = now_s();
+                (void)hipMemcpyAsync(h, d, out_bytes, hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                d2h_s[t] += now_s() - a;
+            }
+            (void)hipFree(d); (void)hipFree(din); (void)hipFree(sink); (void)hipHostFree(h); (void)hipHostFree(hin); (void)hipStreamDestroy(s);
+        });
+    for (std::thread &x : th) x.join();
+    const double wall = now_s() - t0;
+    double dsum = 0, usum = 0;
+    for (int t = 0; t < threads; t++) { dsum += d2h_s[t]; usum += up_s[t]; }
+    std::printf("{\"sim\": {\"threads\": %d, \"rounds\": %d, \"off\": \"%s\", \"ok\": %s, \"wall_ms\": %.1f, \"aggregate_d2h_GBps\": %.2f, "
+                "\"mean_download_ms\": %.2f, \"mean_upload_ms\": %.2f}}\n", threads, rounds, flags, bad.load() ? "false" : "true", wall * 1e3,
+                (double)out_bytes * threads * rounds / wall / 1e9, dsum / (threads * rounds) * 1e3, usum / (threads * rounds) * 1e3);
+    return bad.load() ? 2 : 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !std::strcmp(argv[1], "sim"))
+        return simulate(0, argc > 2 ? std::atoi(argv[2]) : 3, argc > 3 ? std::atoi(argv[3]) : 6, argc > 4 ? argv[4] : "");
     const int dev = argc > 1 ? std::atoi(argv[1]) : 0;
     CHECK(hipSetDevice(dev));
     const size_t cap = (size_t)768 << 20;
