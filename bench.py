@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--out-format", default="bmp", choices=["bmp", "rgb8"],
                     help="what the device writes per picture: the BMP file image the reference's writer would emit (default), or tight RGB8")
     ap.add_argument("--verify", action="store_true", help="check a few pictures against the oracle after the run")
-    ap.add_argument("--e2e-batches", type=int, default=16,
+    ap.add_argument("--e2e-batches", type=int, default=32,
                     help="also run the pipelined batcher (JPEG bytes in host memory -> BMP bytes in pinned host memory, "
                          "PCIe both ways) over this many batches of the workload; 0 = skip.  Reported as pcie_inclusive, never as value")
     args = ap.parse_args()
@@ -367,11 +367,11 @@ def main():
             line["verified_against_oracle"] = bool(R["verify"])
         jpegs = R["jpegs"]
         if world == 1 and args.e2e_batches > 0:
-            # PCIe-inclusive rate: host scan + H2D + kernels + D2H, all overlapped by libpjdpipe (4 GPU slots)
+            # PCIe-inclusive rate: host scan + H2D + kernels + D2H, all overlapped by libpjdpipe (3 GPU slots)
             pipe_jpegs = jpegs * args.e2e_batches
             # warm-up: every slot allocates its HBM pool and page-locks its output buffer once
-            pjd_amd.pipe_run(jpegs=jpegs * 8, batch_images=len(jpegs), scan_threads=8, slots=4, sink=None, device=local_rank)
-            ps = pjd_amd.pipe_run(jpegs=pipe_jpegs, batch_images=len(jpegs), scan_threads=8, slots=4, sink=None, device=local_rank)
+            pjd_amd.pipe_run(jpegs=jpegs * 8, batch_images=len(jpegs), scan_threads=8, slots=3, sink=None, device=local_rank)
+            ps = pjd_amd.pipe_run(jpegs=pipe_jpegs, batch_images=len(jpegs), scan_threads=8, slots=3, sink=None, device=local_rank)
             pjd_amd.pipe_release()
             line["pcie_inclusive"] = {
                 "value": round(ps["pixels"] / ps["wall_s"] / 1e6, 2), "unit": "MPix/s", "out_format": "bmp",

@@ -142,6 +142,9 @@ struct Pipe {
     std::condition_variable latch_cv;
     pjd_pipe_stats st{};
     std::atomic<int> slots_open{0};
+    std::mutex ahead_m;
+    std::condition_variable ahead_cv;
+    int finished_jobs = 0, max_ahead = 8;   // batches scanned (or being scanned) beyond the ones already done with
     bool trace = std::getenv("PJD_PIPE_TRACE") != nullptr;
     double t_run0 = 0;
 
@@ -154,6 +157,10 @@ struct Pipe {
         for (;;) {
             const int i = next_input.fetch_add(1);
             if (i >= (int)in.size()) break;
+            {   // bounded look-ahead: scanned inputs (each holds a copy of its bitstream) wait for the GPU, not the other way round
+                std::unique_lock<std::mutex> l(ahead_m);
+                ahead_cv.wait(l, [&] { return i / o.batch_images < finished_jobs + max_ahead; });
+            }
             Input &x = in[i];
             const double t0 = now_s();
             if (x.path) {
@@ -260,6 +267,8 @@ struct Pipe {
                              stolen ? " (stolen)" : "");
             for (int i = job.first; i < job.first + job.count; i++)
                 if (in[i].sc) { pjd_scanned_free(in[i].sc); in[i].sc = nullptr; }
+            { std::lock_guard<std::mutex> l(ahead_m); finished_jobs++; }
+            ahead_cv.notify_all();
             std::lock_guard<std::mutex> l(stat_m);
             st.create_s += t_create; st.upload_s += t_up; st.exec_s += t_exec; st.download_s += t_down;
             st.n_batches++; st.n_batch_failures += failed ? 1 : 0;
@@ -268,6 +277,7 @@ struct Pipe {
             st.device_batches[d]++; st.device_in_bytes[d] += job.cost; st.n_stolen += stolen ? 1 : 0;
         }
         park_slot(res);
+        if (trace) std::fprintf(stderr, "[pjdpipe] slot of dev %d leaves %.2f\n", devs[d], (now_s() - t_run0) * 1e3);
     }
 
     void sink_worker()
@@ -345,6 +355,11 @@ struct Pipe {
             if (nb > 0) pjd_pipe_assign(cost.data(), nb, (int)devs.size(), dev_of.data());
             for (int k = 0; k < nb; k++) jobs[k]->dev = dev_of[k];
         }
+        {
+            size_t total_slots = 0;
+            for (const std::vector<SlotRes> &r : res) total_slots += r.size();
+            max_ahead = (int)(total_slots + 3);
+        }
         std::vector<std::thread> scanners, slots, sinks;
         for (int k = 0; k < o.sink_threads && o.sink; k++) sinks.emplace_back([this] { sink_worker(); });
         for (size_t d = 0; d < devs.size(); d++)
@@ -354,6 +369,7 @@ struct Pipe {
         if (trace) std::fprintf(stderr, "[pjdpipe] scanners done %.2f\n", (now_s() - t0) * 1e3);
         for (auto &q : ready) q->close();                  // every job has been pushed by now
         for (std::thread &t : slots) t.join();
+        if (trace) std::fprintf(stderr, "[pjdpipe] slots joined %.2f\n", (now_s() - t0) * 1e3);
         sinkq.close();
         for (std::thread &t : sinks) t.join();
         st.wall_s = now_s() - t0;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -213,6 +214,36 @@ void skip_segment(Bytes &in)
     in.pos += cnt;
 }
 
+// Bitstream buffers of freed pjd_scanned objects, kept for the next scans (at most 512 MiB): a batcher scans and frees
+// ~100 KB per picture around the clock, and handing that to malloc/free makes every scan fault fresh pages in and ends
+// a run with the allocator returning gigabytes to the system (100 ms at the end of a 16-batch run, profiles/r02_pcie.md).
+struct EcsCache {
+    std::mutex m;
+    std::vector<std::vector<uint8_t>> free_list;
+    size_t bytes = 0;
+    static constexpr size_t kMaxBytes = (size_t)512 << 20;
+    void take(std::vector<uint8_t> &v, size_t want)
+    {
+        std::lock_guard<std::mutex> l(m);
+        // newest first; a buffer that is too small is still taken (reserve() below grows it once)
+        if (free_list.empty()) return;
+        v.swap(free_list.back());
+        free_list.pop_back();
+        bytes -= v.capacity();
+        (void)want;
+    }
+    void give(std::vector<uint8_t> &v)
+    {
+        if (v.capacity() == 0) return;
+        std::lock_guard<std::mutex> l(m);
+        if (bytes + v.capacity() > kMaxBytes) return;          // the vector frees itself
+        bytes += v.capacity();
+        free_list.emplace_back();
+        free_list.back().swap(v);
+    }
+};
+EcsCache g_ecs_cache;
+
 // Entropy-coded data (reference src/jpeg_scanner.cpp:405-433), run-at-a-time.  Returns false
 // after an error was logged.
 bool entropy_segment(Bytes &in, pjd_scanned &s)
@@ -220,6 +251,7 @@ bool entropy_segment(Bytes &in, pjd_scanned &s)
     const uint8_t *p = in.p;
     const uint64_t n = in.n;
     uint64_t i = in.pos;
+    if (s.ecs.capacity() == 0) g_ecs_cache.take(s.ecs, n - i + 16);
     s.ecs.clear();
     s.ecs.reserve(n - i + 16);
     s.segs.assign(1, 0);
@@ -327,7 +359,12 @@ int pjd_scan_file(const char *path, pjd_scanned **out)
 const pjd_image_desc *pjd_scanned_desc(const pjd_scanned *s) { return &s->d; }
 const char *pjd_scanned_log(const pjd_scanned *s) { return s->log.c_str(); }
 int pjd_scanned_valid(const pjd_scanned *s) { return s->valid ? 1 : 0; }
-void pjd_scanned_free(pjd_scanned *s) { delete s; }
+void pjd_scanned_free(pjd_scanned *s)
+{
+    if (!s) return;
+    g_ecs_cache.give(s->ecs);
+    delete s;
+}
 
 void pjd_scanned_metadata(const pjd_scanned *s, uint32_t *m)
 {
