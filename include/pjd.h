@@ -67,6 +67,10 @@ extern "C" {
                                        (jpeg_scanner.cpp:723), which differs -- and garbles --
                                        when luma sampling is not 1x1.                         */
 #define PJD_F_FORCE_SEQUENTIAL  2u  /* decode with the one-lane exact kernel (debug/diagnosis) */
+#define PJD_F_STANDARD_ZIGZAG   4u  /* zigzag slot 48 -> natural position 58 (ITU T.81) instead of
+                                       the reference's 38 (common.h:16), for coefficients and for
+                                       the quantiser (qt_slot48).  NOT reference-comparable: the
+                                       reference has no such mode, parity for it is unpinned.   */
 
 /* Huffman table as the reference's scanner holds it (jpeg.h:129-134):
  * offsets[k] = number of codes of length <= k (offsets[0] = 0).               */
@@ -102,6 +106,9 @@ typedef struct pjd_image_desc {
      * shard_n_segs == 0 means "all".  The output buffer is always full-size;
      * only the MCUs of the selected segments are written.                      */
     uint32_t shard_first_seg, shard_n_segs;
+    uint32_t qt_slot48[4];             /* DQT entry 48 of each table: the reference's map sends it
+                                          to natural 38, where entry 52 overwrites it, so `qt`
+                                          does not hold it.  Read only with PJD_F_STANDARD_ZIGZAG. */
 } pjd_image_desc;
 
 typedef struct pjd_ctx pjd_ctx;

@@ -47,6 +47,7 @@
 #define PJD_IF_STANDARD_RESTART 1u  // restart every RI-th MCU; else the reference's (y*Wr+x)%RI rule
 #define PJD_IF_SEQUENTIAL       2u  // routed to the exact one-lane kernel up front
 #define PJD_IF_BMP              4u  // output is a BMP file image (else tight RGB8)
+#define PJD_IF_STANDARD_ZIGZAG  8u  // zigzag slot 48 -> natural 58, no slot-52 override (PJD_F_STANDARD_ZIGZAG)
 
 // status word per image: low 8 bits = PJD_ST_* class, bit 8 = "fast path gave up, needs exact kernel"
 #define PJD_STW_NEEDS_EXACT 0x100

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
         for (int j = 0; j < 8; j++) v[j] = rv[j];
         int16_t *t = tile[du];
         const uint16_t *q = qs[comp];
-        if (r == 6) {
+        if (r == 6 && !(im.flags & PJD_IF_STANDARD_ZIGZAG)) {
             // slots 48..55.  Natural position 38 is the target of slot 48 AND slot 52 (the
             // reference's zigzag_map[48] = 38): the later write wins, and an explicit zero
             // written at slot 52 (run/size symbol with size 0) is marked by the sentinel.
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint32_t nat = c_zz[r * 8 + j];
-                t[nat] = (int16_t)pjd_dequant(v[j], q[nat]);
+                const uint32_t nat = (r == 6 && j == 0) ? 58u : c_zz[r * 8 + j];          // r == 6 here: PJD_IF_STANDARD_ZIGZAG
+                t[nat] = (int16_t)pjd_dequant(v[j] == PJD_COEF_SENTINEL ? 0 : v[j], q[nat]);
             }
         }
     }
@@ -563,8 +563,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     const uint32_t n_du = wg.n_mcu * dus;
     const uint32_t RI = im.restart_interval;
 
+    const bool quirk = !(im.flags & PJD_IF_STANDARD_ZIGZAG);    // the reference's zigzag_map[48] = 38 (default)
     if (tid < 192) {
-        const uint32_t nat = c_zz[tid & 63];
+        const uint32_t nat = (!quirk && (tid & 63) == 48) ? 58u : c_zz[tid & 63];
         qz[tid >> 6][tid & 63] = (uint32_t)B.qtab[(size_t)wg.image * 192 + (tid & ~63u) + nat] | (nat << 16);
     }
     // unvisited positions are zero (the reference's buffers start zeroed)
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                     const bool term = (e[k] & 0xf7ffu) == 0;                     // EOB: completes the unit, stores nothing
                     if (!term && slot < 64) {
                         const uint32_t comp = comp_of[u];
-                        if (slot == 52) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
+                        if (slot == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
                         else { const uint32_t qe = qz[comp][slot]; tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu); }
                     }
                 }

@@ -117,6 +117,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         if (out_format == PJD_OUT_BMP) { g.flags |= PJD_IF_BMP; g.out_stride = d.width * 3 + d.width % 4; }
         else g.out_stride = d.width * 3;
         if (d.flags & PJD_F_STANDARD_RESTART) g.flags |= PJD_IF_STANDARD_RESTART;
+        if (d.flags & PJD_F_STANDARD_ZIGZAG) g.flags |= PJD_IF_STANDARD_ZIGZAG;
 
         // ---- quantisation tables: the reference copies QT t only while every t' < t is set
         //      (decoder_host.cpp:173-178); later tables read as zero.  Only the low 16 bits of
@@ -126,6 +127,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             for (int t = 0; t <= d.comp_qt[c]; t++) visible = visible && d.qt_set[t];
             for (int k = 0; k < 64; k++)
                 P.qtab[((size_t)i * 3 + c) * 64 + k] = visible ? (uint16_t)d.qt[d.comp_qt[c]][k] : 0;
+            if ((d.flags & PJD_F_STANDARD_ZIGZAG) && visible) P.qtab[((size_t)i * 3 + c) * 64 + 58] = (uint16_t)d.qt_slot48[d.comp_qt[c]];
         }
 
         // ---- Huffman tables: dedupe the (up to) 3 DC + 3 AC tables the components reference, then find or make

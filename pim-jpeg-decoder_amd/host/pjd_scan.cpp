@@ -135,7 +135,11 @@ void quant_tables(Bytes &in, pjd_scanned &s)
         if (id > 3) return s.reject(": Error Invalid quantization table ID: %u\n", (unsigned)id);
         s.d.qt_set[id] = 1;
         const bool wide = (info >> 4) != 0;
-        for (int k = 0; k < 64; k++) s.d.qt[id][kZigzag[k]] = wide ? in.be16() : (uint32_t)in.get();
+        for (int k = 0; k < 64; k++) {
+            const uint32_t q = wide ? in.be16() : (uint32_t)in.get();
+            s.d.qt[id][kZigzag[k]] = q;
+            if (k == 48) s.d.qt_slot48[id] = q;            // lost in `qt` (entry 52 lands on the same position); PJD_F_STANDARD_ZIGZAG
+        }
         left -= wide ? 128 : 64;
     }
     if (left != 0) s.reject(": Error - DQT invalid\n");

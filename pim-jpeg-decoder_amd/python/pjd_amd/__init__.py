@@ -16,7 +16,7 @@ LIBHOST = os.path.join(LIB_DIR, "libpjdhost.so")
 LIBPIPE = os.path.join(LIB_DIR, "libpjdpipe.so")
 
 OUT_RGB8, OUT_BMP = 0, 1
-F_STANDARD_RESTART, F_FORCE_SEQUENTIAL = 1, 2
+F_STANDARD_RESTART, F_FORCE_SEQUENTIAL, F_STANDARD_ZIGZAG = 1, 2, 4
 MAX_KERNELS = 16
 
 
@@ -38,6 +38,7 @@ class ImageDesc(C.Structure):
         ("seg_offsets", C.c_void_p), ("n_segments", C.c_uint32),
         ("flags", C.c_uint32),
         ("shard_first_seg", C.c_uint32), ("shard_n_segs", C.c_uint32),
+        ("qt_slot48", C.c_uint32 * 4),
     ]
 
 

@@ -73,7 +73,12 @@ class Port:
         L.orc_bmp.restype = C.c_int64
         L.orc_bmp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rgb_from_mcus.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_standard_zigzag.argtypes = [C.c_int]
         self.L = L
+
+    def standard_zigzag(self, on: bool):
+        """NOT the reference's behaviour: zigzag entry 48 -> 58 (tests of PJD_F_STANDARD_ZIGZAG only; switch it off again)."""
+        self.L.orc_set_standard_zigzag(1 if on else 0)
 
     def parse(self, data: bytes, name: str = "x.jpg"):
         """-> dict(info, ecs, metadata, log, handle-free). Scanner only."""

@@ -257,6 +257,41 @@ def test_config2_single_4k_matches_oracle(ctx, port):
             assert np.array_equal(outs[0], plain["rgb"])
 
 
+def test_standard_zigzag_flag(ctx, port):
+    """PJD_F_STANDARD_ZIGZAG: zigzag slot 48 goes to natural position 58 as in ITU T.81, not to 38 as in the reference
+    (src/headers/common.h:16).  NOT reference-comparable -- the reference has no such mode, so PARITY IS UNPINNED here:
+    the check is against the oracle port with the same one-entry change (oracle/jpeg_port.c: orc_set_standard_zigzag),
+    on the parallel path and on the exact kernel, plus a sanity check against an independent decoder (Pillow): the
+    standard map must be the closer one on a picture with energy at those frequencies."""
+    import io
+    import pjd_amd
+    synth = _synth()
+    datas = [synth.make(333, 200, 7, 97, synth.SUB_420, 0, synth.DENSE_DETAIL, True), synth.make(160, 120, 8, 95, synth.SUB_444, 5),
+             golden_bytes("big_500x375_444_q92_opt"), golden_bytes("gray_61x45")]
+    quirk = [port.decode(d)["rgb"] for d in datas]
+    port.standard_zigzag(True)
+    try:
+        want = [port.decode(d)["rgb"] for d in datas]
+    finally:
+        port.standard_zigzag(False)
+    assert [port.decode(d)["rgb"].tobytes() for d in datas] == [q.tobytes() for q in quirk]      # the switch is off again
+    for extra in (0, pjd_amd.F_FORCE_SEQUENTIAL):
+        scanned = [pjd_amd.Scanned(d) for d in datas]
+        for s in scanned:
+            s.desc.flags = pjd_amd.F_STANDARD_ZIGZAG | extra
+        outs, st = ctx.decode([s.desc for s in scanned])
+        assert st == [0] * len(datas)
+        for o, w in zip(outs, want):
+            assert np.array_equal(o, w)
+    assert any(not np.array_equal(q, w) for q, w in zip(quirk, want))
+    PIL = pytest.importorskip("PIL.Image")
+    ref = np.asarray(PIL.open(io.BytesIO(datas[0])).convert("RGB")).astype(np.int32)
+    h, w, _ = ref.shape
+    err_std = np.abs(want[0].reshape(h, w, 3).astype(np.int32) - ref).mean()
+    err_quirk = np.abs(quirk[0].reshape(h, w, 3).astype(np.int32) - ref).mean()
+    assert err_std < err_quirk, (err_std, err_quirk)
+
+
 def test_config5_tile_444_restart_rows_matches_oracle(ctx, port):
     """BASELINE config 5 shape at reduced size: 4:4:4, one restart interval per MCU row."""
     import pjd_amd

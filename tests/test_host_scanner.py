@@ -116,6 +116,33 @@ def test_libpjdpipe_exports_every_declared_symbol():
     pjd_amd.pipe_lib()             # loads together with libpjd / libpjdhost (no compute call)
 
 
+def test_integration_option_a_snippet_compiles(tmp_path):
+    """INTEGRATION.md option A (the literal replacement for the reference's DPU dispatch, src/decoder_host.cpp:268-312):
+    the code block is taken from the document as is and compiled in a stand-alone translation unit that declares
+    nothing but the two vectors of the reference's `Batch` the snippet touches (decoder_host.cpp:24-29)."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = md[md.index("## Option A"):]
+    code = sec[sec.index("```cpp") + 6:]
+    code = code[:code.index("```")]
+    head, body = code[:code.index("// in offloading()")], code[code.index("// in offloading()"):]
+    src = tmp_path / "option_a.cpp"
+    src.write_text("""#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <iostream>
+#include <vector>
+typedef unsigned int uint;
+struct Batch { std::vector<std::vector<short>> mcus; std::vector<std::vector<uint32_t>> metadata; };
+""" + head + "\nint offloading_dispatch(Batch &batch)\n{\n" + body + "\nreturn rc;\n}\n")
+    p = subprocess.run(["g++", "--std=c++11", "-Wall", "-Werror", "-Wno-unused-variable", "-c", str(src), "-I", os.path.join(ROOT, "include"), "-o", str(tmp_path / "option_a.o")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    # and it links against the library it names
+    p = subprocess.run(["g++", "-shared", "-fPIC", "--std=c++11", str(src), "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(pjd_amd.LIBPJD),
+                        "-lpjd", "-Wl,-rpath," + os.path.dirname(pjd_amd.LIBPJD), "-o", str(tmp_path / "option_a.so")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+
+
 def test_pipe_assign_deals_longest_first_to_least_loaded():
     """The multi-device batcher's dealing rule (pjd_pipe_assign, no GPU): LPT on input bytes, deterministic,
     within 4/3 of the best possible makespan (Graham's bound), every device used when there are enough batches."""
