@@ -170,11 +170,9 @@ def test_cli_writes_reference_bmps(tmp_path):
 
 def test_routing_parallel_path_is_the_one_that_runs(ctx):
     """Regular streams must be decoded by the parallel kernels (no silent exact-kernel fallback);
-    broken streams and the no-EOB q100 noise streams must be re-decoded by the exact kernel."""
+    broken streams must be re-decoded by the exact kernel."""
     import pjd_amd
     expect_fallback = {"err_corrupt_3", "err_truncated_eoi_420", "err_truncated_eoi_444"}
-    may_fallback = {"env_128x96_420_q100_opt", "env_200x150_420_q100_opt", "noise_96x80_444_q100", "env_61x45_420_q100_opt",
-                    "env_64x48_420_q100", "env_72x40_420_q100", "noise_96x80_420_q95", "noise_80x96_422_q50_opt"}
     for name in VALID:
         s = _desc(name)
         with ctx.batch([s.desc]) as b:
@@ -190,7 +188,7 @@ def test_routing_parallel_path_is_the_one_that_runs(ctx):
         assert i["n_sequential"] == 0, name
         if name in expect_fallback:
             assert i["n_fallback"] == 1, name
-        elif name not in may_fallback:
+        else:      # every other fixture, the no-EOB q100 noise streams included: no re-decode (tools/gpu_probe.py lists the rounds each needs)
             assert i["n_fallback"] == 0, name
 
 
