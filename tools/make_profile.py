@@ -7,7 +7,7 @@ fetch/ (FETCH_SIZE), write/ (WRITE_SIZE) -- counters are collected in their own 
 the HIP/HSA API.  Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are
 in KiB and wide coalesced reads are under-counted by 2x on gfx950, so read traffic = 2 x FETCH_SIZE.
 
-Derived figures (per kernel, mean per launch):
+Derived figures (per kernel, median over the launches of a pass):
     traffic_bytes    = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
     kernel cycles    = SQ_BUSY_CYCLES / 32          (the counter sums the 32 shader engines of the 8 XCDs)
     valu_issue_frac  = 4 x SQ_INSTS_VALU / (1024 SIMDs x kernel cycles)     a wave64 VALU instruction holds its SIMD 4 cycles
@@ -34,7 +34,8 @@ def counters(d):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 per[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in per.items()}, {k: max(len(v) for v in cs.values()) for k, cs in per.items()}
+    med = lambda v: sorted(v)[len(v) // 2]      # median: a run also holds one-picture launches (the bench decodes its bundled sample first)
+    return {k: {c: med(v) for c, v in cs.items()} for k, cs in per.items()}, {k: max(len(v) for v in cs.values()) for k, cs in per.items()}
 
 
 def main():
@@ -75,7 +76,7 @@ def main():
 
     per_kernel = {}
     alg = bench["roofline"]["algorithmic_bytes_per_launch"] if bench else None
-    md += ["## HBM traffic per launch", "",
+    md += ["## HBM traffic per launch (median over launches)", "",
            "| kernel | FETCH_SIZE KiB (raw) | read MB = 2 x FETCH (gfx950 correction) | WRITE_SIZE KiB | written MB | launches |", "|---|---|---|---|---|---|"]
     tot_r = tot_w = 0.0
     for k in sorted(C):
@@ -93,7 +94,7 @@ def main():
         md += ["", f"Decode kernels together: read {tot_r / 1e6:.0f} MB + written {tot_w / 1e6:.0f} MB = {(tot_r + tot_w) / 1e6:.0f} MB per batch against "
                f"{alg / 1e6:.0f} MB algorithmic (bitstreams read once + pictures written once): x{(tot_r + tot_w) / alg:.2f}"
                f" (x{(tot_r / 2 + tot_w) / alg:.2f} without the read correction)."]
-    md += ["", "## SQ counters per launch (mean)", "",
+    md += ["", "## SQ counters per launch (median)", "",
            "| kernel | VALU insts | SALU | LDS | VMEM rd | VMEM wr | branch | valu_issue_frac | lane_util | wait_frac | LDS bank-conflict cycles / LDS active |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
     for k in sorted(C):
