@@ -12,8 +12,18 @@
 #define PJD_HUFF_LANES     64       // subsequences per wave: lanes exchange states by shuffles, no barriers
 #define PJD_HUFF_WAVES     4        // waves per Huffman workgroup; they share one table set in LDS
 #define PJD_HUFF_THREADS   (PJD_HUFF_LANES * PJD_HUFF_WAVES)
-#define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into)
-#define PJD_WAVE_LDS       (2 * PJD_NCHK * 64 * 4)   // per wave: checkpoints (sync passes) / entry staging (write pass)
+#ifndef PJD_NCHK
+#define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into); a power of two
+#endif
+#ifndef PJD_STAGE_ENTRIES
+#define PJD_STAGE_ENTRIES  32       // entries a lane stages in LDS between flushes (a power of two, multiple of 8)
+#endif
+#define PJD_CHK_BYTES      (2 * PJD_NCHK * 64 * 4)
+#define PJD_STAGE_BYTES    (PJD_STAGE_ENTRIES * 2 * 64)
+// per wave: checkpoints (sync passes) / entry staging (write pass).  LDS sets the kernel's occupancy (every KB here is paid four
+// times per workgroup); measured in profiles/r02_occupancy.md: more LDS costs throughput, less (4 checkpoints, 16 staged
+// entries: 2 KB per wave) gains 1-2 % with batches in flight and loses 2 % alone, so the sizes stay.
+#define PJD_WAVE_LDS       (PJD_CHK_BYTES > PJD_STAGE_BYTES ? PJD_CHK_BYTES : PJD_STAGE_BYTES)
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
 #define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one table set in LDS; larger -> exact kernel
@@ -30,7 +40,6 @@
 // Entries (2 bytes, one per decoded symbol) a lane may emit into its own region; a lane that would need more
 // (< 2 bits per symbol on average) flags its image for the exact kernel.
 #define PJD_LANE_CAP(sub_bytes)   (4 * (sub_bytes) + 64)
-#define PJD_STAGE_ENTRIES  (PJD_WAVE_LDS / 64 / 2)       // entries a lane stages in LDS between flushes (32)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
 // The write pass turns every decoded Huffman symbol into exactly one 16-bit entry:

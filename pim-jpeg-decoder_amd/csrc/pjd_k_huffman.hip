@@ -37,6 +37,8 @@
 // write pass -- invalid code, size or run outside the baseline limits, a segment that ends early or
 // late, a boundary that did not stitch, a lane that does not reproduce its synchronised exit --
 // sets PJD_STW_NEEDS_EXACT and the host re-decodes that image with the one-lane exact kernel.
+#include <cstdlib>
+
 #include "pjd_device_common.h"
 #include "pjd_kernels.h"
 
@@ -288,7 +290,7 @@ __device__ __forceinline__ void stage_flush(const OutCtx &O, uint32_t first_entr
 {
     uint4 *dst = reinterpret_cast<uint4 *>(O.region + first_entry);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PJD_STAGE_ENTRIES / 8; k++) {
         uint4 v;
         v.x = O.stage[(4 * k + 0) * 64]; v.y = O.stage[(4 * k + 1) * 64];
         v.z = O.stage[(4 * k + 2) * 64]; v.w = O.stage[(4 * k + 3) * 64];
@@ -360,9 +362,9 @@ __device__ __forceinline__ void write_span(const uint8_t *lds, const PhaseCtx &P
         if (p >= end_bit || D >= D_end) break;
         const uint32_t e0 = write_step(lds, P, w, p, z, r, x, err, ov, D, O);
         O.n++;
-        if (p >= end_bit || D >= D_end) { O.stage[((O.n >> 1) & 15u) * 64] = e0; break; }
+        if (p >= end_bit || D >= D_end) { O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0; break; }
         const uint32_t e1 = write_step(lds, P, w, p, z, r, x, err, ov, D, O);
-        O.stage[((O.n >> 1) & 15u) * 64] = e0 | (e1 << 16);
+        O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0 | (e1 << 16);
         O.n++;
         if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {
             stage_flush(O, O.n - PJD_STAGE_ENTRIES);
@@ -743,7 +745,11 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t huff_lds_bytes(const PjdDevBatch &b) { return (size_t)b.max_lut_bytes + PJD_HUFF_WAVES * PJD_WAVE_LDS + 16; }
+static size_t huff_lds_bytes(const PjdDevBatch &b)
+{
+    static const size_t extra = [] { const char *e = std::getenv("PJD_EXTRA_LDS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();   // occupancy experiments
+    return (size_t)b.max_lut_bytes + PJD_HUFF_WAVES * PJD_WAVE_LDS + 16 + extra;
+}
 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 {
