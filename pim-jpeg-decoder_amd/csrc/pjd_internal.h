@@ -98,6 +98,7 @@ struct PjdDevImage {
     uint32_t idct_mcus;                // MCUs per IDCT workgroup
     uint32_t first_mcu, last_mcu;      // MCU range this shard decodes: [first_mcu, last_mcu)
     uint32_t tset;                     // table set (PjdDevTset) of this image
+    uint32_t sub_bytes;                // subsequence size of THIS image (<= the batch's, which sizes word rows and lane regions)
     uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1 of the set
     uint8_t  pad_[2];
 };

@@ -559,12 +559,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     g.seg = 0; g.end_bit = g.seg_end_bit = g.base_bit = 0;
     g.words = (pjd_gptr)readfirstlane_u64((uint64_t)(B.words + (size_t)w * B.word_rows * 64));
     uint32_t seg_first_du = 0, seg_n_du = 0;
+    const uint32_t sub_bytes = rfl(im.sub_bytes);        // of this wave's image
     if (g.valid) {
         const PjdDevSub sb = B.lanes[g.q];
         g.seg = sb.seg & 0x7fffffffu;
         g.seg_first = (sb.seg >> 31) != 0;
         const PjdDevSegment sg = B.segs[g.seg];
-        const uint32_t end_byte = sb.byte_start + B.sub_bytes < sg.byte_end ? sb.byte_start + B.sub_bytes : sg.byte_end;
+        const uint32_t end_byte = sb.byte_start + sub_bytes < sg.byte_end ? sb.byte_start + sub_bytes : sg.byte_end;
         g.seg_last = end_byte == sg.byte_end;
         g.base_bit = sb.byte_start * 8;
         g.end_bit = (end_byte - sb.byte_start) * 8;
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     ChkCtx K;
     K.state = area + l;
     K.rem = area + PJD_NCHK * 64 + l;
-    K.chk_bits = B.sub_bytes * 8 / PJD_NCHK;
+    K.chk_bits = sub_bytes * 8 / PJD_NCHK;
     for (int j = 0; j < PJD_NCHK; j++) { K.state[j * 64] = 0xffffffffu; K.rem[j * 64] = 0; }
     const bool first_is_head = __shfl((uint32_t)g.seg_first, 0) != 0;     // lane 0 starts a restart segment: no predecessor wave
     const uint32_t last_lane = hw.n_lanes - 1;

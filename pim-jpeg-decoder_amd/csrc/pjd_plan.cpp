@@ -75,6 +75,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     const uint32_t SB = P.sub_bytes;
 
     uint64_t ecs_off = 0, out_off = 0, du_total = 0, dense_seq = 0, lut_off = 0;
+    uint32_t sb_max = SB;                          // largest per-image subsequence: sizes the word rows and the lane regions
     std::map<std::string, uint32_t> tset_of;       // raw bytes of a deduplicated table list -> table set
     std::vector<char> tset_parallel;               // per set: the two-level tables fit the parallel decoder
     for (int i = 0; i < n; i++) {
@@ -239,6 +240,33 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         g.seg_base = (uint32_t)P.segs.size();
         g.lane_base = (uint32_t)P.subs.size();
         g.hwave_base = (uint32_t)P.hwaves.size();
+        // Subsequence size of this image: the batch's, nudged so that the image's lanes fill whole waves (a wave holds lanes of
+        // one image; at 832 B an ImageNet-sized picture is ~2.1 waves' worth, i.e. three waves, the last nearly empty).
+        uint32_t SBi = SB;
+        if (!sequential && !sub_bytes_override) {
+            auto seg_len = [&](uint32_t k) {
+                const uint64_t b0 = (RI != 0) ? d.seg_offsets[k] : 0, b1 = (RI != 0 && k + 1 < nseg_total) ? d.seg_offsets[k + 1] : d.ecs_len;
+                return (uint32_t)(b1 - b0);
+            };
+            auto lanes_for = [&](uint32_t S) {
+                uint64_t nl = 0;
+                for (uint32_t k = seg_lo; k < seg_hi; k++) { const uint32_t len = seg_len(k); nl += len ? (len + S - 1) / S : 1; }
+                return nl;
+            };
+            const uint64_t n0 = lanes_for(SB);
+            if (n0 > PJD_HUFF_LANES / 2 && n0 % PJD_HUFF_LANES != 0) {
+                const uint64_t kw = (n0 + PJD_HUFF_LANES / 2) / PJD_HUFF_LANES;           // nearest number of whole waves
+                uint32_t best = SB;
+                // smallest multiple of 64 bytes (within -30 % / +45 % of the batch's size) whose lanes fit kw waves
+                const uint32_t lo = SB * 7 / 10 / 64 * 64 > PJD_SUB_BYTES_MIN ? SB * 7 / 10 / 64 * 64 : PJD_SUB_BYTES_MIN;
+                const uint32_t hi = SB * 29 / 20 < PJD_SUB_BYTES_MAX ? SB * 29 / 20 : PJD_SUB_BYTES_MAX;
+                for (uint32_t S = lo; S <= hi; S += 64)
+                    if (lanes_for(S) <= kw * PJD_HUFF_LANES) { best = S; break; }
+                if (lanes_for(best) <= kw * PJD_HUFF_LANES) SBi = best;
+            }
+        }
+        g.sub_bytes = SBi;
+        if (SBi > sb_max) sb_max = SBi;
         if (!sequential) {
             for (uint32_t k = seg_lo; k < seg_hi; k++) {
                 PjdDevSegment sg;
@@ -253,10 +281,10 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                 const uint32_t seg_index = (uint32_t)P.segs.size();
                 P.segs.push_back(sg);
                 uint32_t len = sg.byte_end - sg.byte_start;
-                uint32_t nsub = len ? (len + SB - 1) / SB : 1;
+                uint32_t nsub = len ? (len + SBi - 1) / SBi : 1;
                 for (uint32_t j = 0; j < nsub; j++) {
                     PjdDevSub q;
-                    q.byte_start = sg.byte_start + j * SB;
+                    q.byte_start = sg.byte_start + j * SBi;
                     q.seg = seg_index | (j == 0 ? 0x80000000u : 0u);
                     P.subs.push_back(q);
                 }
@@ -310,8 +338,9 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     // the lane-word kernel copies PJD_WORD_ROWS words from every lane's first byte, whatever the lane's length
     P.ecs_buf_bytes = align_up(ecs_off + PJD_SUB_BYTES_MAX + 64, 256);
     P.n_du = du_total;
-    P.n_ent = (uint64_t)P.subs.size() * PJD_LANE_CAP(SB) + 16;
-    P.n_words = (uint64_t)P.hwaves.size() * PJD_WORD_ROWS(SB) * 64;
+    P.sub_bytes = sb_max;
+    P.n_ent = (uint64_t)P.subs.size() * PJD_LANE_CAP(sb_max) + 16;
+    P.n_words = (uint64_t)P.hwaves.size() * PJD_WORD_ROWS(sb_max) * 64;
     P.dense_du = dense_seq;
     P.out_buf_bytes = align_up(out_off, 256);
     P.n_dcblk = (P.subs.size() + PJD_DC_BLOCK - 1) / PJD_DC_BLOCK;
