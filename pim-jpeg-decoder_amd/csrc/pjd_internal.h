@@ -10,7 +10,9 @@
 #define PJD_SUB_BYTES_MIN  128      // Huffman subsequence (bytes of bitstream per decode lane): chosen per batch
 #define PJD_SUB_BYTES_MAX  1024     //   by the planner (multiple of 64 in this range), see pjd_plan.cpp
 #define PJD_HUFF_LANES     64       // subsequences per wave: lanes exchange states by shuffles, no barriers
+#ifndef PJD_HUFF_WAVES
 #define PJD_HUFF_WAVES     4        // waves per Huffman workgroup; they share one table set in LDS
+#endif
 #define PJD_HUFF_THREADS   (PJD_HUFF_LANES * PJD_HUFF_WAVES)
 #ifndef PJD_NCHK
 #define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into); a power of two
