@@ -11,20 +11,21 @@
 #define PJD_SUB_BYTES_MAX  1024     //   by the planner (multiple of 64 in this range), see pjd_plan.cpp
 #define PJD_HUFF_LANES     64       // subsequences per wave: lanes exchange states by shuffles, no barriers
 #ifndef PJD_HUFF_WAVES
-#define PJD_HUFF_WAVES     4        // waves per Huffman workgroup; they share one table set in LDS
+#define PJD_HUFF_WAVES     2        // waves per Huffman workgroup; they share one table set in LDS
 #endif
 #define PJD_HUFF_THREADS   (PJD_HUFF_LANES * PJD_HUFF_WAVES)
 #ifndef PJD_NCHK
-#define PJD_NCHK           8        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into); a power of two
+#define PJD_NCHK           4        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into); a power of two
 #endif
 #ifndef PJD_STAGE_ENTRIES
-#define PJD_STAGE_ENTRIES  32       // entries a lane stages in LDS between flushes (a power of two, multiple of 8)
+#define PJD_STAGE_ENTRIES  16       // entries a lane stages in LDS between flushes (a power of two, multiple of 8)
 #endif
 #define PJD_CHK_BYTES      (2 * PJD_NCHK * 64 * 4)
 #define PJD_STAGE_BYTES    (PJD_STAGE_ENTRIES * 2 * 64)
-// per wave: checkpoints (sync passes) / entry staging (write pass).  LDS sets the kernel's occupancy (every KB here is paid four
-// times per workgroup); measured in profiles/r02_occupancy.md: more LDS costs throughput, less (4 checkpoints, 16 staged
-// entries: 2 KB per wave) gains 1-2 % with batches in flight and loses 2 % alone, so the sizes stay.
+// per wave: checkpoints (sync passes) / entry staging (write pass).  LDS sets the kernel's occupancy; measured in
+// profiles/r02_occupancy.md: more LDS per workgroup costs throughput at once, and 2 waves per workgroup with 2 KB wave areas
+// (4 checkpoints, 16 staged entries) measured best with batches in flight (+1 % on the default input, +5 % on the lighter one
+// against 4 waves with 4 KB areas), equal within noise for one batch at a time.
 #define PJD_WAVE_LDS       (PJD_CHK_BYTES > PJD_STAGE_BYTES ? PJD_CHK_BYTES : PJD_STAGE_BYTES)
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
