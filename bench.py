@@ -266,6 +266,13 @@ def main():
             barrier()
             r["dt_serial"] = time.perf_counter() - t0
         r["info"] = batch.info()
+        # whole-job totals: ranks decode different seeded batches, so sum what each one really processed per step
+        tot = [float(r["info"]["pixels"]), float(r["info"]["ecs_bytes"]), float(r["info"]["n_entries"])]
+        if world > 1 and not split:
+            tt = torch.tensor(tot, dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            tot = [float(x) for x in tt.tolist()]
+        r["tot"] = tot
         if full:
             # per-kernel durations, HIP events on the library's own stream (ungraphed launches of the same work)
             ktimes, ktotal, reps = {}, 0.0, 5
@@ -296,9 +303,12 @@ def main():
         """Throughput figures of one measurement (whole job: all ranks)."""
         info, dt, k = r["info"], r["dt"], r["steps"]
         mult = 1 if r.get("split") else world        # a split picture is counted once (every rank's plan names the whole picture)
-        o = {"value": round(mult * info["pixels"] * k / dt / 1e6, 2), "unit": "MPix/s", "ms_per_step": round(dt / k * 1e3, 4),
-             "ecs_GBps": round(world * info["ecs_bytes"] * k / dt / 1e9, 2),
-             "huffman_symbols_per_s": round(world * info["n_entries"] * k / dt, 0),
+        pix, ecs, ent = r["tot"]                     # summed over ranks (a split picture: rank 0's plan names the whole picture)
+        if r.get("split"):
+            ecs, ent = world * ecs, world * ent      # every rank holds and decodes its own slice (approximately equal shares)
+        o = {"value": round(pix * k / dt / 1e6, 2), "unit": "MPix/s", "ms_per_step": round(dt / k * 1e3, 4),
+             "ecs_GBps": round(ecs * k / dt / 1e9, 2),
+             "huffman_symbols_per_s": round(ent * k / dt, 0),
              "bytes_per_pixel": round(info["ecs_bytes"] / info["pixels"], 3), "table_sets": info["n_table_sets"],
              "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
              "exact_kernel_images": info["n_sequential"] + info["n_fallback"]}
