@@ -693,8 +693,19 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     }
     __syncthreads();
 
-    // ---- DC prediction over the range (reference src/jpeg_scanner.cpp:485-486) and the slot-52 rule
-    if (wv == 0) {
+#if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 1      // timing experiments only (tools/r2_occ.sh): pictures are wrong
+    if (tile[0][0] == 12345) B.out[0] = 1;
+    return;
+#endif
+    // ---- DC prediction over the range (reference src/jpeg_scanner.cpp:485-486) by wave 0, while the other waves already do
+    //      the row pass of rows 1..7 (only row 0 holds the DC coefficient) and the slot-52 rule (natural 38 lies in row 4)
+    if (wv != 0) {
+        for (uint32_t i = tid - 64; i < n_du * 7; i += PJD_IDCT_THREADS - 64) {
+            const uint32_t u = i / 7, r = 1 + (i - u * 7);
+            if (r == 4 && s52[u]) tile[u][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[u] & 0xffffu), qz[comp_of[u]][48] & 0xffffu);   // slot 48 -> natural 38
+            pjd_tile_row(tile, u, r);
+        }
+    } else {
         const uint32_t d0 = wg.first_mcu * dus;
         uint32_t cy = pred0[0], cc = (pred0[1] & 0xffffu) | (pred0[2] << 16);   // predictors entering the next group of 64 units
         for (uint32_t base = 0; base < n_du; base += 64) {
@@ -719,7 +730,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             if (on) {
                 const uint32_t dcv = comp == 0 ? ty : (comp == 1 ? tc : tc >> 16);
                 tile[u][0] = (int16_t)pjd_dequant((int)(int16_t)dcv, qz[comp][0] & 0xffffu);
-                if (s52[u]) tile[u][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[u] & 0xffffu), qz[comp][48] & 0xffffu);   // slot 48 -> natural 38
             }
             cy = __shfl(ty, 63); cc = __shfl(tc, 63);
         }
@@ -730,10 +740,18 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         mcu_xy[tid] = (my << 16) | (m - my * im.mcux);
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) pjd_tile_row(tile, i >> 3, i & 7);
+#if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 2
+    if (tile[0][0] == 12345) B.out[0] = 1;
+    return;
+#endif
+    for (uint32_t u = tid; u < n_du; u += PJD_IDCT_THREADS) pjd_tile_row(tile, u, 0);
     __syncthreads();
     for (uint32_t i = tid; i < n_du * 8; i += PJD_IDCT_THREADS) pjd_tile_col(tile, i >> 3, i & 7);
     __syncthreads();
+#if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 3
+    if (tile[0][0] == 12345) B.out[0] = 1;
+    return;
+#endif
     pjd_colour_dispatch(tile, mcu_xy, B, im, wg, tid);
 }
 
