@@ -20,7 +20,7 @@ def main():
     ap.add_argument("dir")
     ap.add_argument("--alone", default="", help="name=ms,... durations of the kernels running alone (for the comparison column)")
     a = ap.parse_args()
-    f = glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True)[0]
+    f = sorted(glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]   # the newest run
     ev = []
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].split("(")[0]

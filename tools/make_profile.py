@@ -30,7 +30,8 @@ SHORT = {"pjd_k_huff_lanes": "huff_lanes", "pjd_k_idct_colour_lanes": "idct_colo
 
 def counters(d):
     per = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                          # the newest run only (gpurun merges into an existing directory)
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 per[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -50,8 +51,8 @@ def main():
     for ln in open(os.path.join(a.dir, "stats.log")).read().splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             bench = json.loads(ln)
-    stats_csv = glob.glob(os.path.join(a.dir, "stats", "**", "*kernel_stats.csv"), recursive=True)
-    stats = open(stats_csv[0]).read().strip().splitlines() if stats_csv else []
+    stats_csv = sorted(glob.glob(os.path.join(a.dir, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    stats = open(stats_csv[-1]).read().strip().splitlines() if stats_csv else []
     C, N = {}, {}
     for sub in ("sq1", "sq2", "sq3", "fetch", "write"):
         c, n = counters(os.path.join(a.dir, sub))
