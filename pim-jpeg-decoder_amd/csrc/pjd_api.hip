@@ -27,10 +27,12 @@
 // batches then allocates nothing); bounded by pool_cap, freed at pjd_close.
 struct PoolBlock { void *p; size_t bytes; };
 struct Pool {
+    std::mutex m;                          // the owner takes and gives; any context of the device may flush (out of memory)
     std::vector<PoolBlock> free_blocks;
     size_t bytes = 0;
     void *take(size_t want, size_t &got)
     {
+        std::lock_guard<std::mutex> l(m);
         int best = -1;
         for (size_t k = 0; k < free_blocks.size(); k++) {
             const size_t sz = free_blocks[k].bytes;
@@ -43,7 +45,19 @@ struct Pool {
         free_blocks.erase(free_blocks.begin() + best);
         return p;
     }
-    void give(void *p, size_t sz) { free_blocks.push_back({p, sz}); bytes += sz; }
+    bool give(void *p, size_t sz, size_t cap)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (bytes + sz > cap) return false;
+        free_blocks.push_back({p, sz}); bytes += sz;
+        return true;
+    }
+    template <class F> void flush(F release)            // hand everything cached back to the runtime
+    {
+        std::lock_guard<std::mutex> l(m);
+        for (PoolBlock &k : free_blocks) release(k.p);
+        free_blocks.clear(); bytes = 0;
+    }
 };
 
 struct pjd_ctx {
@@ -67,6 +81,10 @@ struct pjd_ctx {
 
 namespace {
 
+// every open context, so that a context that runs out of HBM can make the others of its device give their caches back
+std::mutex g_ctx_m;
+std::vector<pjd_ctx *> g_ctxs;
+
 int pool_dev_alloc(pjd_ctx *ctx, void **out, size_t bytes, std::vector<PoolBlock> &owned)
 {
     if (bytes == 0) bytes = 16;
@@ -74,9 +92,11 @@ int pool_dev_alloc(pjd_ctx *ctx, void **out, size_t bytes, std::vector<PoolBlock
     void *p = ctx->dev_pool.take(bytes, got);
     if (!p) {
         hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess && !ctx->dev_pool.free_blocks.empty()) {          // give cached memory back and retry
-            for (PoolBlock &k : ctx->dev_pool.free_blocks) hipFree(k.p);
-            ctx->dev_pool.free_blocks.clear(); ctx->dev_pool.bytes = 0;
+        if (e != hipSuccess) {                                                // cached memory of every context on this device goes back; retry
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> l(g_ctx_m);
+            for (pjd_ctx *c : g_ctxs)
+                if (c->device == ctx->device) c->dev_pool.flush([](void *q) { (void)hipFree(q); });
             e = hipMalloc(&p, bytes);
         }
         if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return PJD_E_NOMEM; }
@@ -162,6 +182,7 @@ int pjd_open(int device_ordinal, pjd_ctx **out)
     if (pg) c->pool_cap = (size_t)std::atoll(pg) << 30;
     const char *sb = std::getenv("PJD_SUB_BYTES");
     c->sub_bytes_override = sb ? (uint32_t)std::atoi(sb) : 0;
+    { std::lock_guard<std::mutex> l(g_ctx_m); g_ctxs.push_back(c); }
     *out = c;
     return PJD_OK;
 }
@@ -169,10 +190,15 @@ int pjd_open(int device_ordinal, pjd_ctx **out)
 void pjd_close(pjd_ctx *ctx)
 {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> l(g_ctx_m);
+        for (size_t k = 0; k < g_ctxs.size(); k++)
+            if (g_ctxs[k] == ctx) { g_ctxs.erase(g_ctxs.begin() + k); break; }
+    }
     hipSetDevice(ctx->device);
     if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
-    for (PoolBlock &k : ctx->dev_pool.free_blocks) hipFree(k.p);
-    for (PoolBlock &k : ctx->pin_pool.free_blocks) hipHostFree(k.p);
+    ctx->dev_pool.flush([](void *q) { (void)hipFree(q); });
+    ctx->pin_pool.flush([](void *q) { (void)hipHostFree(q); });
     delete ctx;
 }
 
@@ -203,14 +229,10 @@ void pjd_batch_destroy(pjd_batch *b)
     if (b->graph_exec) hipGraphExecDestroy(b->graph_exec);
     if (b->graph) hipGraphDestroy(b->graph);
     pjd_ctx *ctx = b->ctx;
-    for (PoolBlock &k : b->dev_blocks) {
-        if (ctx->dev_pool.bytes + k.bytes <= ctx->pool_cap) ctx->dev_pool.give(k.p, k.bytes);
-        else hipFree(k.p);
-    }
-    for (PoolBlock &k : b->pin_blocks) {
-        if (ctx->pin_pool.bytes + k.bytes <= ctx->pool_cap / 4) ctx->pin_pool.give(k.p, k.bytes);
-        else hipHostFree(k.p);
-    }
+    for (PoolBlock &k : b->dev_blocks)
+        if (!ctx->dev_pool.give(k.p, k.bytes, ctx->pool_cap)) hipFree(k.p);
+    for (PoolBlock &k : b->pin_blocks)
+        if (!ctx->pin_pool.give(k.p, k.bytes, ctx->pool_cap / 4)) hipHostFree(k.p);
     delete b;
 }
 

@@ -346,6 +346,14 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.n_dcblk = (P.subs.size() + PJD_DC_BLOCK - 1) / PJD_DC_BLOCK;
     P.lut_buf_bytes = align_up(lut_off + 16, 256);
     if (P.ecs_buf_bytes >= (1ull << 40)) { err = "batch bitstream too large"; return PJD_E_ARG; }
+    // every byte a lane can make the kernels read lies inside the bitstream buffer: pjd_k_lane_words copies PJD_WORD_ROWS words
+    // from each lane's first byte (the decoders then only touch those rows); checked here, once per batch, not assumed
+    {
+        const uint64_t reach = (uint64_t)PJD_WORD_ROWS(sb_max) * 4;
+        for (const PjdDevImage &g : P.images)
+            for (uint32_t q = g.lane_base; q < g.lane_base + g.n_lane; q++)
+                if (g.ecs_off + P.subs[q].byte_start + reach > P.ecs_buf_bytes) { err = "internal: a Huffman lane would read past the bitstream buffer"; return PJD_E_ARG; }
+    }
     if (P.subs.size() >= (1ull << 31) || P.n_ent >= (1ull << 40)) { err = "batch has too many Huffman lanes"; return PJD_E_ARG; }
     return PJD_OK;
 }
