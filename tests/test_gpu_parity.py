@@ -362,6 +362,26 @@ def test_dense_optimised_set_matches_oracle(ctx, port):
         assert o.tobytes() == port.decode(j)["bmp"]
 
 
+def test_default_bench_batch_all_pictures_match_oracle(ctx, port):
+    """bench.py's default batch at full size (1024 pictures, 0.58 B/px, a table set per picture; per-picture subsequence
+    sizes, 2-wave workgroups): every BMP equals the oracle's, nothing falls back, the entry count is the symbol count."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = synth.cfg3_imagenet_like(1024, seed=3, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_BMP) as b:
+        b.upload(); b.decode()
+        outs, st = b.download_packed()
+        info = b.info()
+    assert st == [0] * 1024 and info["n_sequential"] == 0 and info["n_fallback"] == 0
+    assert info["n_table_sets"] >= 1000 and sum(info["flag_waves"]) == 0
+    assert info["n_entries"] > 2 * info["n_data_units"]          # at least a DC symbol and an EOB (or a last coefficient) per unit
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        same = list(ex.map(lambda i: outs[i].tobytes() == port.decode(jpegs[i])["bmp"], range(1024)))
+    assert all(same), [i for i, ok in enumerate(same) if not ok][:10]
+
+
 def test_config3_batch_properties(ctx, port):
     """BASELINE config 3 at full size (1024 images): per-image results equal single-image decodes
     (batch independence), decoding twice is idempotent, a sample equals the oracle."""
