@@ -386,7 +386,7 @@ def main():
             line["pcie_inclusive"] = {
                 "value": round(ps["pixels"] / ps["wall_s"] / 1e6, 2), "unit": "MPix/s", "out_format": "bmp",
                 "inputs": ps["n_inputs"], "batches": ps["n_batches"], "wall_ms": round(ps["wall_s"] * 1e3, 2),
-                "d2h_GBps": round(ps["out_bytes"] / ps["wall_s"] / 1e9, 2),
+                "d2h_GBps": round(ps["out_bytes"] / ps["wall_s"] / 1e9, 2), "exact_kernel_images": ps["n_exact_images"],
                 "worker_ms": {k[:-2]: round(ps[k] * 1e3, 1) for k in ("scan_s", "create_s", "upload_s", "exec_s", "download_s")},
                 "note": "JPEG bytes in host memory -> BMP bytes in page-locked host memory; pictures are not consumed further"}
         if world == 1 and not args.no_cpu_baseline:

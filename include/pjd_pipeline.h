@@ -70,6 +70,8 @@ typedef struct pjd_pipe_stats {
     uint64_t n_stolen;                               /* batches run by another device than the one they were dealt to */
     uint64_t device_batches[PJD_PIPE_MAX_DEVICES];   /* batches run per entry of `devices`     */
     uint64_t device_in_bytes[PJD_PIPE_MAX_DEVICES];  /* input bytes of those batches           */
+    uint64_t n_exact_images;                         /* pictures decoded by the exact one-lane kernel (routed up front or
+                                                        re-decoded after the parallel decoder flagged them)                 */
 } pjd_pipe_stats;
 
 /* Returns PJD_OK, PJD_E_NODEVICE if no slot could open the device, PJD_E_ARG.                 */

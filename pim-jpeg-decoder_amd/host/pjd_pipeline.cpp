@@ -217,7 +217,7 @@ struct Pipe {
                 else { rejected++; emit(i, -1, nullptr, 0, &latch); }
             }
             double t_create = 0, t_up = 0, t_exec = 0, t_down = 0;
-            uint64_t pixels = 0, ecs = 0, outb = 0, decoded = 0;
+            uint64_t pixels = 0, ecs = 0, outb = 0, decoded = 0, exact = 0;
             bool failed = false;
             if (!idx.empty()) {
                 pjd_batch *b = nullptr;
@@ -244,7 +244,7 @@ struct Pipe {
                 t_down = now_s() - t0;
                 if (rc == PJD_OK) {
                     pjd_batch_info info;
-                    if (pjd_batch_get_info(b, &info) == PJD_OK) { pixels = info.pixels; ecs = info.ecs_bytes; outb = info.out_bytes; }
+                    if (pjd_batch_get_info(b, &info) == PJD_OK) { pixels = info.pixels; ecs = info.ecs_bytes; outb = info.out_bytes; exact = (uint64_t)(info.n_sequential + info.n_fallback); }
                     for (size_t k = 0; k < idx.size(); k++)
                         emit(idx[k], status[k], pinned + pjd_batch_output_offset(b, (int)k), pjd_batch_output_size(b, (int)k), &latch);
                     decoded = idx.size();
@@ -274,6 +274,7 @@ struct Pipe {
             st.n_batches++; st.n_batch_failures += failed ? 1 : 0;
             st.n_decoded += decoded; st.n_rejected += rejected;
             st.pixels += pixels; st.ecs_bytes += ecs; st.out_bytes += outb;
+            st.n_exact_images += exact;
             st.device_batches[d]++; st.device_in_bytes[d] += job.cost; st.n_stolen += stolen ? 1 : 0;
         }
         park_slot(res);

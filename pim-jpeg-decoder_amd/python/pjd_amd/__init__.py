@@ -350,7 +350,8 @@ class PipeStats(C.Structure):
                 ("n_batches", C.c_uint64), ("n_batch_failures", C.c_uint64),
                 ("pixels", C.c_uint64), ("in_bytes", C.c_uint64), ("ecs_bytes", C.c_uint64), ("out_bytes", C.c_uint64),
                 ("n_devices", C.c_uint64), ("n_stolen", C.c_uint64),
-                ("device_batches", C.c_uint64 * PIPE_MAX_DEVICES), ("device_in_bytes", C.c_uint64 * PIPE_MAX_DEVICES)]
+                ("device_batches", C.c_uint64 * PIPE_MAX_DEVICES), ("device_in_bytes", C.c_uint64 * PIPE_MAX_DEVICES),
+                ("n_exact_images", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k.startswith("device_") else getattr(self, k)) for k, _ in self._fields_}

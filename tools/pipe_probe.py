@@ -32,7 +32,7 @@ def main():
         ps = pjd_amd.pipe_run(jpegs=jpegs * args.batches, batch_images=len(jpegs), scan_threads=args.scan_threads, slots=slots, sink=None)
         pjd_amd.pipe_release()
         print(json.dumps({"slots": slots, "MPix_per_s": round(ps["pixels"] / ps["wall_s"] / 1e6, 1), "d2h_GBps": round(ps["out_bytes"] / ps["wall_s"] / 1e9, 2),
-                          "wall_ms": round(ps["wall_s"] * 1e3, 1),
+                          "wall_ms": round(ps["wall_s"] * 1e3, 1), "exact_kernel_images": ps["n_exact_images"],
                           "worker_ms_per_batch": {k[:-2]: round(ps[k] * 1e3 / ps["n_batches"], 2) for k in ("scan_s", "create_s", "upload_s", "exec_s", "download_s")}}), flush=True)
 
 
