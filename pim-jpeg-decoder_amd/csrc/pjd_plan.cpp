@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 
 namespace {
@@ -49,8 +50,10 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     // Subsequence size.  A decoder started at a wrong position falls into step with the true one only when bit position,
     // zigzag slot AND the phase inside the MCU all agree; measured, that takes about two MCUs' worth of stream on average
     // with a long tail (4:2:0: ~160 B at 80 B per MCU, several times that for dense high-quality streams).  A lane should
-    // be several times that long -- 5.5 MCUs' worth here -- or most lanes need more than one re-sync round; but a small
-    // batch needs enough lanes to fill 256 CUs.
+    // be several times that long -- 8 MCUs' worth here (measured on the default batch: 3.5 / 4.5 / 5.5 / 6.5 / 8 / 10 MCUs ->
+    // 65.0 / 64.0 / 64.7 / 65.8 / 68.8 / 68.3 GPix/s in flight, 6.55 / 6.71 / 6.63 / 6.72 / 6.25 / 6.24 ms alone; subsequences
+    // of up to 2048 bytes were not better than the 1024-byte cap) -- or most lanes need more than one re-sync round; but a
+    // small batch needs enough lanes to fill 256 CUs.
     {
         uint64_t total = 0, mcus = 0;
         for (int i = 0; i < n; i++) {
@@ -58,8 +61,9 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             const uint32_t hs = images[i].h_samp ? images[i].h_samp : 1, vs = images[i].v_samp ? images[i].v_samp : 1;
             mcus += (uint64_t)((images[i].width + 8 * hs - 1) / (8 * hs)) * ((images[i].height + 8 * vs - 1) / (8 * vs));
         }
-        const uint32_t by_total = total >= (64u << 20) ? 1024u : (total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u));
-        uint64_t by_density = mcus ? (total * 11 / 2 / mcus + 63) / 64 * 64 : 512;
+        const uint32_t by_total = total >= (64u << 20) ? (uint32_t)PJD_SUB_BYTES_MAX : (total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u));
+        static const uint64_t mcus_x2 = [] { const char *e = std::getenv("PJD_SUB_MCUS_X2"); const int v = e ? std::atoi(e) : 0; return (uint64_t)(v > 0 ? v : 16); }();   // experiments: subsequence = this many half-MCUs of stream
+        uint64_t by_density = mcus ? (total * mcus_x2 / 2 / mcus + 63) / 64 * 64 : 512;
         if (by_density < PJD_SUB_BYTES_MIN) by_density = PJD_SUB_BYTES_MIN;
         if (by_density > PJD_SUB_BYTES_MAX) by_density = PJD_SUB_BYTES_MAX;
         uint32_t sb = by_total < by_density ? by_total : (uint32_t)by_density;
