@@ -7,8 +7,8 @@ One process per GPU (the driver launches N ranks with torch.distributed.run); ev
 OWN batch (weak scaling, no data-path collective: images are independent).  A step = one pass of the
 whole hot path (Huffman entropy decode -> dequantise -> IDCT -> upsample -> YCbCr->RGB) over one
 batch whose bitstreams, tables and work lists are already resident in HBM; pictures stay in HBM.
-By default three identical batches are resident and steps rotate over them, each batch on its own HIP stream
-(`--in-flight 3`), so step i is issued while step i-1 still runs -- a serving loop; every step's results are
+By default four identical batches are resident and steps rotate over them, each batch on its own HIP stream
+(`--in-flight 4`), so step i is issued while step i-1 still runs -- a serving loop; every step's results are
 drained and checked (`pjd_batch_sync`) before its batch is decoded again.  `one_batch_in_flight` reports the
 same K steps strictly serialised, and the per-kernel durations / `roofline` come from serialised launches too.
 Rank 0 prints ONE JSON line.  Beside the contract fields it carries `roofline` (dominant kernel: algorithmic
@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--images", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=8192)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="resident batches decoded round-robin, each on its own HIP stream: step i is issued while step i-1 is "
                          "still running, as a serving loop would (1 = strictly one step after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

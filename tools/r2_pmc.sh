@@ -14,8 +14,8 @@ timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTI
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_LDS_IDX_ACTIVE SQ_INSTS_SENDMSG --kernel-trace --output-format csv -d "$OUT/sq3" -- $CMD > "$OUT/sq3.log" 2>&1; echo "sq3 rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1; echo "write rc=$?"
-# kernel trace of the default mode (three batches in flight): which kernels overlap (tools/inflight_overlap.py)
-CMD3="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 3 --e2e-batches 0 --no-cpu-baseline --steps 12"
+# kernel trace of the default mode (four batches in flight): which kernels overlap (tools/inflight_overlap.py)
+CMD3="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 4 --e2e-batches 0 --no-cpu-baseline --steps 16"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/inflight" -- $CMD3 > "$OUT/inflight.log" 2>&1; echo "inflight rc=$?"
 # keep the merge small: the per-dispatch CSVs are enough
 find "$OUT" -name "*.db" -delete
