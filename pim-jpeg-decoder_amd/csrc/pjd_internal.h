@@ -40,9 +40,10 @@
 // Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
 // the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
 #define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
-// Entries (2 bytes, one per decoded symbol) a lane may emit into its own region; a lane that would need more
-// (< 2 bits per symbol on average) flags its image for the exact kernel.
-#define PJD_LANE_CAP(sub_bytes)   (4 * (sub_bytes) + 64)
+// Entries (2 bytes, one per decoded symbol) a lane may emit into its own region: one per BIT of its subsequence, plus the
+// symbol that may have started before it and a flush unit of slack.  Every symbol consumes at least one bit, so no stream
+// can overflow it (very low qualities with optimised tables reach 1.5 bits per symbol: a 1-bit EOB after a 2-bit DC code).
+#define PJD_LANE_CAP(sub_bytes)   (8 * (sub_bytes) + 64)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
 // The write pass turns every decoded Huffman symbol into exactly one 16-bit entry:

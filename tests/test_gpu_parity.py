@@ -555,6 +555,27 @@ def test_random_streams_one_batch_match_oracle(ctx, port):
     assert info["n_fallback"] == 0
 
 
+def test_sparsest_streams_stay_on_the_parallel_path(ctx, port):
+    """Quality 5 with optimised tables: a data unit is a 1-2-bit DC code and a 1-bit EOB, i.e. more than five symbols per
+    byte of stream.  The lane regions hold one entry per bit, so these pictures do not overflow them into the exact kernel
+    (found by tools/fuzz_parity.py when the regions held one entry per two bits)."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = [synth.make(444, 460, 91, 5, synth.SUB_422, 0, 1.0, True), synth.make(649, 513, 92, 5, synth.SUB_444, 0, 1.0, True),
+             synth.make(381, 350, 93, 5, synth.SUB_420, 72, 1.0, True), synth.make(300, 200, 94, 5, synth.SUB_GREY, 0, 1.0, True)]
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    scanned[2].desc.flags = pjd_amd.F_STANDARD_RESTART
+    for group in ([0, 1, 2, 3], [0], [1], [2], [3]):
+        with ctx.batch([scanned[i].desc for i in group]) as b:
+            b.upload(); b.decode()
+            outs, st = b.download()
+            info = b.info()
+        assert info["n_fallback"] == 0 and info["n_sequential"] == 0 and sum(info["flag_waves"]) == 0, (group, info["flag_waves"])
+        for i, o, s in zip(group, outs, st):
+            want = port.decode(jpegs[i] if i != 2 else synth.make(381, 350, 93, 5, synth.SUB_420, 0, 1.0, True))
+            assert s == want["huff_rc"] and np.array_equal(o, want["rgb"]), i
+
+
 def test_two_batches_in_flight_on_two_contexts(port):
     """bench.py's default mode: two contexts (two HIP streams), decodes issued alternately without waiting for the
     other one; both produce the oracle's pictures every time."""
