@@ -555,6 +555,38 @@ def test_random_streams_one_batch_match_oracle(ctx, port):
     assert info["n_fallback"] == 0
 
 
+def test_random_corrupted_streams_match_oracle(ctx, port):
+    """Error paths under random damage (a cut-down tools/fuzz_parity.py --corrupt): 200 seeded pictures with 1-3 bytes of the
+    second half of the file overwritten.  The scanner accepts exactly the files the oracle's accepts; for those, the Huffman
+    error class and the (partial) picture equal the oracle's (reference: the picture decoded so far is still written,
+    src/decoder_host.cpp:181)."""
+    import pjd_amd
+    synth = _synth()
+    rng = np.random.default_rng(4242)
+    jpegs = []
+    for k in range(200):
+        w, h = int(rng.integers(8, 301)), int(rng.integers(8, 301))
+        sub = int(rng.choice([synth.SUB_444, synth.SUB_422, synth.SUB_420, synth.SUB_440, synth.SUB_GREY]))
+        ri = int(rng.choice([0, 0, 3, 11]))
+        ba = bytearray(synth.make(w, h, 5000 + k, int(rng.choice([25, 75, 95])), sub, ri, float(rng.choice([1.0, synth.DENSE_DETAIL])), bool(k & 1)))
+        for _ in range(int(rng.integers(1, 4))):
+            ba[int(rng.integers(len(ba) // 2, len(ba) - 2))] = int(rng.integers(0, 256))
+        jpegs.append(bytes(ba))
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    valid = [bool(port.parse(j)["info"]["valid"]) for j in jpegs]
+    assert [bool(s.valid) for s in scanned] == valid
+    idx = [i for i, v in enumerate(valid) if v]
+    assert len(idx) > 100
+    outs, st = ctx.decode([scanned[i].desc for i in idx])
+    n_err = 0
+    for i, o, s in zip(idx, outs, st):
+        want = port.decode(jpegs[i])
+        assert s == want["huff_rc"], (i, s, want["huff_rc"])
+        assert np.array_equal(o, want["rgb"]), i
+        n_err += s != 0
+    assert n_err > 10          # the damage does reach the entropy decoder
+
+
 def test_sparsest_streams_stay_on_the_parallel_path(ctx, port):
     """Quality 5 with optimised tables: a data unit is a 1-2-bit DC code and a 1-bit EOB, i.e. more than five symbols per
     byte of stream.  The lane regions hold one entry per bit, so these pictures do not overflow them into the exact kernel

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--n", type=int, default=3000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=250)
+    ap.add_argument("--corrupt", type=int, default=0, help="overwrite this many random bytes in the second half of every file: error paths "
+                    "(scanner accept/reject set, Huffman error classes, partial pictures) against the oracle")
     a = ap.parse_args()
     import oracle_lib
     import pjd_amd
@@ -47,11 +49,29 @@ def main():
             ri = int(rng.choice([0, 0, 0, 1, 2, 7, mcux, 3 * mcux]))
             detail = float(rng.choice([1.0, 1.0, synth.DENSE_DETAIL]))
             opt = bool(rng.random() < 0.5)
-            jpegs.append(synth.make(w, h, 10_000 * a.seed + k, q, sub, ri, detail, opt))
-            std = ri != 0 and sub in (synth.SUB_422, synth.SUB_420, synth.SUB_440) and k % 2 == 0
+            jp = synth.make(w, h, 10_000 * a.seed + k, q, sub, ri, detail, opt)
+            if a.corrupt:
+                ba = bytearray(jp)
+                for _ in range(a.corrupt):
+                    ba[int(rng.integers(len(ba) // 2, len(ba) - 2))] = int(rng.integers(0, 256))
+                jp = bytes(ba)
+            jpegs.append(jp)
+            std = (not a.corrupt) and ri != 0 and sub in (synth.SUB_422, synth.SUB_420, synth.SUB_440) and k % 2 == 0
             flags.append(pjd_amd.F_STANDARD_RESTART if std else 0)
             plain.append(synth.make(w, h, 10_000 * a.seed + k, q, sub, 0, detail, opt) if std else None)
         scanned = [pjd_amd.Scanned(j) for j in jpegs]
+        if a.corrupt:                                          # the scanners must agree on what is a JPEG; the rest goes on
+            keep = []
+            for i, (j, s) in enumerate(zip(jpegs, scanned)):
+                ov = bool(port.parse(j)["info"]["valid"])
+                if ov != bool(s.valid):
+                    bad += 1
+                    print(f"SCANNER MISMATCH picture {b0 + i}: oracle valid {ov}, scanner valid {s.valid}", flush=True)
+                elif ov:
+                    keep.append(i)
+            rejected = len(jpegs) - len(keep)
+            jpegs = [jpegs[i] for i in keep]; scanned = [scanned[i] for i in keep]; flags = [flags[i] for i in keep]; plain = [plain[i] for i in keep]
+            print(f"    corrupted: {rejected} rejected by both scanners, {len(keep)} decoded", flush=True)
         for s, f in zip(scanned, flags):
             s.desc.flags = f
         fmt = pjd_amd.OUT_BMP if (b0 // a.batch) % 2 else pjd_amd.OUT_RGB8
