@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void pjd_k_lane_words(PjdDevBatch B)
     const PjdDevHuffWave hw = B.hwaves[wv];
     const PjdDevImage &im = B.images[hw.image];
     const uint32_t l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
-    const uint32_t rows = B.word_rows;
-    uint32_t *dst = B.words + (size_t)wv * rows * 64;
+    const uint32_t rows = PJD_WORD_ROWS(im.sub_bytes);          // of this image: at most B.word_rows, the stride between waves
+    uint32_t *dst = B.words + (size_t)wv * B.word_rows * 64;
     const bool valid = l < hw.n_lanes;
     const uint8_t *src = B.ecs + im.ecs_off + (valid ? B.lanes[hw.first_lane + l].byte_start : 0u);
     for (uint32_t k = k0; k < rows; k += 4) {
