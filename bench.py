@@ -175,10 +175,18 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # rehearsal on a one-GPU box (never set by the driver): PJD_BENCH_DEVICE puts every rank on that device and
+    # PJD_BENCH_BACKEND=gloo replaces RCCL, so that the multi-rank control flow (barriers, reductions, totals) can be run
+    if "PJD_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PJD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PJD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import pjd_amd
     out_fmt = pjd_amd.OUT_BMP if args.out_format == "bmp" else pjd_amd.OUT_RGB8

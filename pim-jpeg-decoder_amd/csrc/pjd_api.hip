@@ -408,10 +408,12 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     KernelTimer kt{timings, s, {}, {}};
     const bool parallel = !P.hwgs.empty();
     kt.mark("start");
-    HIP_TRY(ctx, hipMemcpyAsync(b->dev.status, b->d_status_init, sizeof(int32_t) * P.images.size(), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(ctx, hipMemsetAsync(b->dev.stats, 0, 16 * sizeof(unsigned long long), s));
-    if (b->dev.dbg) HIP_TRY(ctx, hipMemsetAsync(b->dev.dbg, 0, P.hwaves.size() * 32 * sizeof(uint32_t), s));
-    if (parallel) HIP_TRY(ctx, hipMemsetAsync(b->d_opstate, 0, b->opstate_bytes, s));
+    // One kernel of ours instead of two runtime memsets and a copy: status words from their initial values, statistics and
+    // the words the Huffman waves publish to each other zeroed.  Inside a captured graph the runtime's small memset nodes are
+    // not safe to replay next to other users of the runtime in the process: a 128-byte memset node replayed a 16-byte pattern
+    // of stale pointers instead of zeros (seen with torch/gloo active before the capture; tools/r2 rehearsal of cfg5split).
+    pjd_launch_reset(s, b->dev, b->d_status_init, parallel ? b->d_opstate : nullptr, parallel ? b->opstate_bytes / 8 : 0,
+                     b->dev.dbg ? (uint32_t)(P.hwaves.size() * 32) : 0u);
     kt.mark("reset");
     if (parallel) {
         pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
@@ -423,7 +425,7 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     }
     if (!b->seq_list.empty()) {
         // images routed to the exact kernel: dense int16 scratch, cleared first (unvisited slots are zero)
-        HIP_TRY(ctx, hipMemsetAsync(b->dev.coef, 0, P.dense_du * 64 * sizeof(int16_t), s));
+        pjd_launch_zero(s, b->dev.coef, P.dense_du * 64 * sizeof(int16_t));      // a kernel, not a memset node: see the reset above
         pjd_launch_huff_sequential(s, b->dev, b->d_seq_list, b->d_seq_base, (uint32_t)b->seq_list.size());
         pjd_launch_idct_colour(s, b->dev, b->d_iwgs_dense, b->d_seq_base, (uint32_t)P.iwgs_dense.size());
         kt.mark("exact_path");

@@ -102,6 +102,40 @@ void pjd_launch_copy_out(hipStream_t s, const void *src, void *dst_mapped, uint6
     if (n16) hipLaunchKernelGGL(pjd_k_copy_out, dim3(wgs), dim3(256), 0, s, (const pjd_u32x4 *)src, (pjd_u32x4 *)dst_mapped, n16);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-decode reset: status words from their initial values (images routed to the exact kernel start flagged), the
+// statistics, the words the Huffman waves publish to each other, the debug timeline.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pjd_k_reset(PjdDevBatch B, const int32_t *__restrict__ status_init, uint64_t *__restrict__ opstate,
+                                                   uint32_t opstate_words, uint32_t dbg_words)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B.n_images) B.status[i] = status_init[i];
+    if (i < 16) B.stats[i] = 0;
+    if (i < opstate_words) opstate[i] = 0;
+    for (uint32_t k = i; k < dbg_words; k += gridDim.x * 256) B.dbg[k] = 0;
+}
+
+__global__ __launch_bounds__(256) void pjd_k_zero(uint4 *__restrict__ p, uint64_t n16)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+void pjd_launch_zero(hipStream_t s, void *p, size_t bytes)
+{
+    const uint64_t n16 = bytes / 16;
+    if (!n16) return;
+    const uint64_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(pjd_k_zero, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, (uint4 *)p, n16);
+}
+
+void pjd_launch_reset(hipStream_t s, const PjdDevBatch &b, const int32_t *status_init, uint64_t *opstate, size_t opstate_words, uint32_t dbg_words)
+{
+    size_t n = b.n_images > 16 ? b.n_images : 16;
+    if (opstate_words > n) n = opstate_words;
+    hipLaunchKernelGGL(pjd_k_reset, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, status_init, opstate, (uint32_t)opstate_words, dbg_words);
+}
+
 void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus)
 {
     hipLaunchKernelGGL(pjd_k_dpu_payload, dim3(n_dpus * 25), dim3(128), 0, s, metadata, mcus);

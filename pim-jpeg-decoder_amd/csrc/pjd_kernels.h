@@ -43,6 +43,8 @@ struct PjdDevBatch {
 
 // ---- back end (pjd_k_backend.hip) ------------------------------------------------
 void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mcus, int n_dpus);
+void pjd_launch_zero(hipStream_t s, void *p, size_t bytes);          // bytes: a multiple of 16
+void pjd_launch_reset(hipStream_t s, const PjdDevBatch &b, const int32_t *status_init, uint64_t *opstate, size_t opstate_words, uint32_t dbg_words);   // per-decode state
 void pjd_launch_copy_out(hipStream_t s, const void *src, void *dst_mapped, uint64_t bytes);   // HBM -> mapped page-locked host memory
 // dense input (exact path): wgs[k].pad_ = index into dense_base[] (data unit 0 of that image's scratch)
 void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, const uint64_t *dense_base, uint32_t n_wg);
