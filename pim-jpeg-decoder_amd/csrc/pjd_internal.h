@@ -34,7 +34,9 @@
 #define PJD_SYNC_MAX_ITERS 72       // re-sync rounds per wave before giving up (a non-merging chain moves one lane per round)
 #define PJD_DC_BLOCK       256      // lanes per DC-prediction scan block
 #define PJD_IDCT_THREADS   256
-#define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup
+#ifndef PJD_IDCT_MAX_DU
+#define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup (<= PJD_IDCT_THREADS)
+#endif
 #define PJD_COEF_SENTINEL  (-32768) // "slot 52 was visited with an explicit 0" (zigzag quirk)
 
 // Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
