@@ -390,9 +390,12 @@ int run_pipe(Pipe &p, const pjd_pipe_opts *opts, pjd_pipe_stats *stats)
     if (p.o.out_format != PJD_OUT_BMP && p.o.out_format != PJD_OUT_RGB8) return PJD_E_ARG;
     if (p.o.devices && p.o.n_devices > 0) {
         if (p.o.n_devices > PJD_PIPE_MAX_DEVICES) return PJD_E_ARG;
+        // PJD_PIPE_ALLOW_DUP_DEVICES=1 (tests on a one-GPU box): the same ordinal may be listed several times and then counts as
+        // several devices, so that dealing, per-device queues and stealing run for real
+        const bool dup_ok = std::getenv("PJD_PIPE_ALLOW_DUP_DEVICES") != nullptr;
         for (int k = 0; k < p.o.n_devices; k++) {
             const int d = p.o.devices[k];
-            if (d < 0 || std::find(p.devs.begin(), p.devs.end(), d) != p.devs.end()) return PJD_E_ARG;   // negative / listed twice
+            if (d < 0 || (!dup_ok && std::find(p.devs.begin(), p.devs.end(), d) != p.devs.end())) return PJD_E_ARG;   // negative / listed twice
             p.devs.push_back(d);
         }
     } else {

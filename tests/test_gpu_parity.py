@@ -502,6 +502,37 @@ def test_pipeline_devices_list_of_one_equals_single_device(tmp_path):
     assert p.returncode == 1 and "Error - Invalid arguments" in p.stdout
 
 
+def test_pipeline_two_device_groups_on_one_gpu(monkeypatch):
+    """The multi-device machinery of the batcher for real on a one-GPU box: with PJD_PIPE_ALLOW_DUP_DEVICES the ordinal 0 listed
+    twice counts as two devices (own slots, own queue each).  Batches of very different sizes are dealt longest-first, both
+    groups work, every picture equals the reference's, and the per-device counters add up."""
+    import threading
+    import pjd_amd
+    monkeypatch.setenv("PJD_PIPE_ALLOW_DUP_DEVICES", "1")
+    names = sorted(VALID, key=lambda n: len(golden_bytes(n)))          # ascending size, like the CLI: batch costs differ a lot
+    jpegs = [golden_bytes(n) for n in names]
+    got, lock = {}, threading.Lock()
+
+    def sink(index, name, log, status, data):
+        with lock:
+            got[index] = None if data is None else hashlib.sha256(data.tobytes()).hexdigest()
+
+    st = pjd_amd.pipe_run(jpegs=jpegs, names=[n + ".jpg" for n in names], batch_images=5, slots=2, scan_threads=3, sink_threads=2, sink=sink,
+                          devices=[0, 0])
+    pjd_amd.pipe_release()
+    nb = (len(names) + 4) // 5
+    assert st["n_devices"] == 2 and st["n_batches"] == nb and st["n_batch_failures"] == 0
+    assert st["device_batches"][0] + st["device_batches"][1] == nb and min(st["device_batches"][:2]) >= 1
+    assert st["device_in_bytes"][0] + st["device_in_bytes"][1] == sum(len(j) for j in jpegs)
+    # the deal: what pjd_pipe_assign gives for these batch costs, unless a group ran dry and took from the other
+    cost = [sum(len(j) for j in jpegs[k:k + 5]) for k in range(0, len(jpegs), 5)]
+    dealt = pjd_amd.pipe_assign(cost, 2)
+    if st["n_stolen"] == 0:
+        assert st["device_batches"][0] == dealt.count(0) and st["device_in_bytes"][0] == sum(c for c, d in zip(cost, dealt) if d == 0)
+    for i, n in enumerate(names):
+        assert got[i] == MANIFEST[n]["bmp_sha256"], n
+
+
 def test_download_packed_equals_download(ctx):
     import pjd_amd
     scanned = [_desc(n) for n in VALID[:9]]
