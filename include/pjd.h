@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define PJD_VERSION 1
+/* ABI version: bumped whenever a struct in this header changes size or layout (pjd_image_desc gained qt_slot48 and
+ * pjd_batch_info grew in version 2; version 3 adds the coefficient download and the exact-path figures of pjd_batch_info).
+ * A caller built against another version must not pass its structs: check pjd_version() == PJD_VERSION after loading.     */
+#define PJD_VERSION 3
 
 /* ---- error codes (library level) ---------------------------------------- */
 #define PJD_OK              0
@@ -185,6 +188,17 @@ uint64_t pjd_batch_output_size(pjd_batch *b, int image);
 void *pjd_batch_device_output(pjd_batch *b, int image);      /* device pointer (HBM)          */
 void *pjd_batch_device_status(pjd_batch *b);                 /* int32[n_images] in HBM        */
 void pjd_batch_destroy(pjd_batch *b);
+
+/* ---- stage-level parity (debug; not on the product path) ------------------------------------ *
+ * The coefficients of one image as the entropy decoder left them, in the layout of the reference's
+ * MCU_buffer after decode_Huffman_data (jpeg_scanner.cpp:733-741): n_dpus x int16[19200], index
+ * blk16 * 768 + component * 256 + position * 64 + natural index (through the reference's zigzag_map,
+ * common.h:9-18), absolute DC values, zero where nothing was decoded.  n_dpus x 19200 =
+ * pjd_coefficients_size(...) as decoder_host.cpp:125-128 sizes it.  Works after pjd_batch_decode for
+ * images of either path (lane streams / exact kernel); an image the parallel decoder handed to the
+ * exact kernel is decoded once more for this call.  Synchronises the stream.                          */
+uint64_t pjd_coefficients_size(uint32_t width, uint32_t height, uint8_t h_samp, uint8_t v_samp);   /* in int16 */
+int  pjd_batch_download_coefficients(pjd_batch *b, int image, int16_t *out, uint64_t capacity_int16);
 
 /* One call: create + upload + decode + download + destroy.                    */
 int  pjd_decode_batch(pjd_ctx *ctx, const pjd_image_desc *images, int n_images,

@@ -68,7 +68,7 @@ typedef struct pjd_pipe_stats {
     uint64_t pixels, in_bytes, ecs_bytes, out_bytes;
     uint64_t n_devices;                              /* devices that opened                    */
     uint64_t n_stolen;                               /* batches run by another device than the one they were dealt to */
-    uint64_t device_batches[PJD_PIPE_MAX_DEVICES];   /* batches run per entry of `devices`     */
+    uint64_t device_batches[PJD_PIPE_MAX_DEVICES];   /* batches run per entry of `devices` (an entry whose device did not open stays 0) */
     uint64_t device_in_bytes[PJD_PIPE_MAX_DEVICES];  /* input bytes of those batches           */
     uint64_t n_exact_images;                         /* pictures decoded by the exact one-lane kernel (routed up front or
                                                         re-decoded after the parallel decoder flagged them)                 */

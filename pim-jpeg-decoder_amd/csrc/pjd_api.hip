@@ -338,7 +338,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     b->dev.n_iwg = (uint32_t)P.iwgs.size(); b->dev.n_dcblk = (uint32_t)P.n_dcblk;
     b->dev.sub_bytes = P.sub_bytes;
     b->dev.word_rows = PJD_WORD_ROWS(P.sub_bytes);
-    b->dev.lane_cap = PJD_LANE_CAP(P.sub_bytes);
+    b->dev.lane_cap = P.lane_cap;
     b->dev.max_lut_bytes = P.max_lut_bytes;
     *out = b;
     return PJD_OK;
@@ -734,6 +734,65 @@ void *pjd_batch_device_output(pjd_batch *b, int image)
 }
 
 void *pjd_batch_device_status(pjd_batch *b) { return b ? (void *)b->dev.status : nullptr; }
+
+uint64_t pjd_coefficients_size(uint32_t width, uint32_t height, uint8_t h_samp, uint8_t v_samp)
+{
+    // reference src/jpeg_scanner.cpp:257-262 (mcu_*_real) and src/decoder_host.cpp:125-128 (DPUs needed, 100 positions each)
+    uint64_t w = (width + 7) / 8, h = (height + 7) / 8;
+    if (h_samp == 2 && (w & 1)) w++;
+    if (v_samp == 2 && (h & 1)) h++;
+    const uint64_t pw = (w + 1) / 2 * 2, ph = (h + 1) / 2 * 2;
+    return (pw * ph + 99) / 100 * 19200;
+}
+
+int pjd_batch_download_coefficients(pjd_batch *b, int image, int16_t *out, uint64_t capacity_int16)
+{
+    if (!b || !out || image < 0 || (size_t)image >= b->plan.images.size()) return PJD_E_ARG;
+    if (!b->decoded) { b->ctx->err = "download_coefficients before decode"; return PJD_E_STATE; }
+    pjd_ctx *ctx = b->ctx;
+    PjdPlan &P = b->plan;
+    hipSetDevice(ctx->device);
+    int rc = settle(b);
+    if (rc != PJD_OK) return rc;
+    const PjdDevImage &g = P.images[image];
+    const uint64_t n16 = pjd_coefficients_size(g.width, g.height, (uint8_t)g.hs, (uint8_t)g.vs);
+    if (capacity_int16 < n16) { ctx->err = "download_coefficients: buffer smaller than pjd_coefficients_size"; return PJD_E_ARG; }
+    hipStream_t s = ctx->stream;
+    int16_t *d_out = nullptr, *scratch = nullptr;
+    uint32_t *d_list = nullptr; uint64_t *d_base = nullptr;
+    auto cleanup = [&] { hipFree(d_out); hipFree(scratch); hipFree(d_list); hipFree(d_base); };
+    if (hipMalloc((void **)&d_out, n16 * sizeof(int16_t)) != hipSuccess) { ctx->err = "hipMalloc failed (coefficients)"; return PJD_E_NOMEM; }
+    pjd_launch_zero(s, d_out, n16 * sizeof(int16_t));                  // 19200 int16 per DPU: a multiple of 16 bytes
+    const uint32_t n_du = (g.last_mcu - g.first_mcu) * g.dus_per_mcu, first_du = g.first_mcu * g.dus_per_mcu;
+    const bool routed = P.host[image].sequential;
+    const bool fell_back = !routed && (b->h_status[image] & PJD_STW_NEEDS_EXACT);
+    hipError_t e = hipSuccess;
+    if (routed) {
+        pjd_launch_coefdump_dense(s, b->dev, (uint32_t)image, b->dev.coef + g.dense_base * 64, first_du, n_du, d_out);
+    } else if (fell_back) {
+        // the scratch settle() used is gone: run the exact kernel for this one image again (its status word does not change)
+        const uint32_t one = (uint32_t)image; const uint64_t zero = 0;
+        if (hipMalloc((void **)&scratch, (size_t)n_du * 64 * sizeof(int16_t)) != hipSuccess || hipMalloc((void **)&d_list, sizeof one) != hipSuccess ||
+            hipMalloc((void **)&d_base, sizeof zero) != hipSuccess) { cleanup(); ctx->err = "hipMalloc failed (coefficients scratch)"; return PJD_E_NOMEM; }
+        pjd_launch_zero(s, scratch, (size_t)n_du * 64 * sizeof(int16_t));
+        e = hipMemcpyAsync(d_list, &one, sizeof one, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_base, &zero, sizeof zero, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            PjdDevBatch dv = b->dev;
+            dv.coef = scratch;
+            pjd_launch_huff_sequential(s, dv, d_list, d_base, 1);
+            pjd_launch_coefdump_dense(s, dv, (uint32_t)image, scratch, first_du, n_du, d_out);
+        }
+    } else {
+        pjd_launch_coefdump_lanes(s, b->dev, (uint32_t)image, g.n_iwg, d_out);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n16 * sizeof(int16_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) { ctx->err = std::string("download_coefficients: ") + hipGetErrorString(e); return PJD_E_HIP; }
+    return PJD_OK;
+}
 
 int pjd_decode_batch(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, int out_format,
                      uint8_t *const *out, int32_t *status)

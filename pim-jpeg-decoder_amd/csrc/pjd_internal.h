@@ -42,10 +42,13 @@
 // Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
 // the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
 #define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
-// Entries (2 bytes, one per decoded symbol) a lane may emit into its own region: one per BIT of its subsequence, plus the
-// symbol that may have started before it and a flush unit of slack.  Every symbol consumes at least one bit, so no stream
-// can overflow it (very low qualities with optimised tables reach 1.5 bits per symbol: a 1-bit EOB after a 2-bit DC code).
-#define PJD_LANE_CAP(sub_bytes)   (8 * (sub_bytes) + 64)
+// Entries (2 bytes, one per decoded symbol) a lane may emit into its own region.  Every symbol consumes at least `min_bits` bits
+// of stream -- the smallest (code length + value bits) over the Huffman tables the batch uses, computed by the planner; 1 if a
+// table has a 1-bit code for a size-0 symbol -- so a lane of `sub_bytes` bytes emits at most 8 * sub_bytes / min_bits entries,
+// plus the symbol that may have started before it and a flush unit of slack.  (Annex-K tables: 2 bits; optimised tables of very
+// low qualities reach 1.5 bits per symbol on average -- a 1-bit EOB after a 2-bit DC code -- but no single symbol below 1.)
+// The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.  A multiple of 16 entries: regions stay 32-byte aligned.
+#define PJD_LANE_CAP(sub_bytes, min_bits)   ((((8u * (sub_bytes) + (min_bits) - 1) / (min_bits) + 64u) + 15u) & ~15u)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
 // The write pass turns every decoded Huffman symbol into exactly one 16-bit entry:

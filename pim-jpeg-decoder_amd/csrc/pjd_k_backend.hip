@@ -2,12 +2,14 @@
 //
 //   pjd_k_dpu_payload   the reference's per-DPU contract, one workgroup per 16x16 "block"
 //                       (reference src/decoder_dpu.c:82-390)
-//   pjd_k_dc_local /    DC prediction as a two-level segmented scan over MCUs
-//   pjd_k_dc_carry      (reference src/jpeg_scanner.cpp:485-486,723-727)
-//   pjd_k_idct_colour_sparse / pjd_k_idct_colour
-//                       fused de-zigzag + dequantise + 8x8 IDCT + chroma upsample + YCbCr->RGB +
-//                       raster store (reference src/decoder_dpu.c:158-390 and src/bmp_writer.cpp:43-65
-//                       for the BMP row order).  _sparse reads the parallel decoder's entry stream;
+//   pjd_k_reset / _zero / _copy_out
+//                       per-decode state reset (kernels of ours, not runtime memset nodes), packed download by a kernel
+//   pjd_k_lane_dc_local /  DC prediction: the entropy decoder leaves DC DIFFERENCES and per-lane sums; the predictors at every
+//   pjd_k_lane_dc_carry    lane start are a two-level segmented scan over lanes (reference src/jpeg_scanner.cpp:485-486,723-727)
+//   pjd_k_idct_colour_lanes / pjd_k_idct_colour
+//                       fused de-zigzag + dequantise + 8x8 IDCT + chroma upsample + YCbCr->RGB + raster / BMP store
+//                       (reference src/decoder_dpu.c:158-390 and src/bmp_writer.cpp:43-65 for the BMP row order).
+//                       _lanes parses the parallel decoder's lane streams (one 16-bit entry per symbol);
 //                       the other reads the dense int16 scratch the exact kernel fills.
 //
 // HBM-bound integer work: coefficients are read once with 16-byte loads, tiles

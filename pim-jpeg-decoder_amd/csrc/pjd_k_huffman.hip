@@ -18,8 +18,9 @@
 //                        byte, transposed per wave ([word][lane]): a lane's refill is one dword of a row its
 //                        neighbours read too, so the 64 per-lane streams of a wave cost a few cache lines per
 //                        load instead of 64
-//   pjd_k_huff_lanes     one wave = 64 subsequences of one image; a workgroup = 4 waves that share one table set
-//                        in LDS (nothing else: waves never meet at a barrier after the tables are loaded).
+//   pjd_k_huff_lanes     one wave = 64 subsequences of one image; a workgroup = up to PJD_HUFF_WAVES (2) consecutive waves
+//                        that share one table set in LDS (nothing else: waves never meet at a barrier after the tables
+//                        are loaded).
 //                        A  speculative pass over the own subsequence (state only, no output) that leaves
 //                           PJD_NCHK checkpoints of the trajectory in LDS
 //                        R  re-sync rounds: a lane restarts from its predecessor's exit state and stops as soon
@@ -389,7 +390,7 @@ struct LaneGeom {
     pjd_gptr words;                // wave-uniform: row 0 of the wave's transposed word rows
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][wave areas 4 x PJD_WAVE_LDS][ticket]
+extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][wave areas PJD_HUFF_WAVES x PJD_WAVE_LDS][ticket]
 
 // Lanes have different origins, so states are exchanged as bit positions relative to the image's ecs.
 struct WaveState { uint32_t p_img, cz, cnt; };
@@ -426,19 +427,22 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
 }
 
 // ---------------------------------------------------------------------------------------------
-// Segmented combine used for data-unit counts: element = (value, head flag); a head resets.
-__device__ __forceinline__ void seg_combine(uint32_t av, uint32_t af, uint32_t &bv, uint32_t &bf)   // b = a (+) b
+// Segmented combine used for data-unit counts: element = (value, head flag); a head resets.  Sums SATURATE at `cap`
+// (= the image's unit count + 1, below 2^28): speculative lanes also count "units" in whatever bytes follow the picture's last
+// unit, and a long such tail must read as "past the end" everywhere, never wrap back into the picture's range (a look-back
+// descriptor carries 28 bits).  min(a + b, cap) is associative on non-negative values, so scan and look-back stay exact below cap.
+__device__ __forceinline__ void seg_combine(uint32_t av, uint32_t af, uint32_t &bv, uint32_t &bf, uint32_t cap)   // b = a (+) b
 {
-    if (!bf) bv += av;
+    if (!bf) { const uint32_t t = bv + av; bv = t < cap ? t : cap; }
     bf |= af;
 }
 
-__device__ __forceinline__ void wave_seg_scan(uint32_t &v, uint32_t &f)      // inclusive, 64 lanes
+__device__ __forceinline__ void wave_seg_scan(uint32_t &v, uint32_t &f, uint32_t cap)      // inclusive, 64 lanes
 {
     const uint32_t lane = threadIdx.x & 63;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t ov = __shfl_up(v, off), of = __shfl_up(f, off);
-        if ((int)lane >= off) seg_combine(ov, of, v, f);
+        if ((int)lane >= off) seg_combine(ov, of, v, f, cap);
     }
 }
 
@@ -622,13 +626,14 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     const uint64_t ts3 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 
     // ---- C: counts.  Inside the wave: segmented scan of data units ...
+    const uint32_t du_cap = rfl(im.n_du) + 1;                 // "past the last unit"; the planner keeps it below 2^28
     uint32_t cnt = 0, v = 0, f = 0;
     if (g.valid) {
         cnt = S.cnt;
-        v = cnt;
-        if (g.seg_first) { f = 1; v += seg_first_du; }
+        v = cnt < du_cap ? cnt : du_cap;
+        if (g.seg_first) { f = 1; v = seg_first_du + v < du_cap ? seg_first_du + v : du_cap; }
     }
-    wave_seg_scan(v, f);
+    wave_seg_scan(v, f, du_cap);
     const uint32_t agg_v = __shfl(v, 63), agg_f = __shfl(f, 63);
     // ... across the image's waves: decoupled look-back
     uint32_t du_in = 0;
@@ -657,29 +662,35 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
             // lane l holds wave hi-l: larger l = earlier.  Suffix-combine so that lane 0 = X_k (+) ... (+) X_0.
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t ov = __shfl_down(xv, off), of = __shfl_down(xf, off);
-                if ((int)l + off < 64) seg_combine(ov, of, xv, xf);
+                if ((int)l + off < 64) seg_combine(ov, of, xv, xf, du_cap);
             }
             const uint32_t wvv = __shfl(xv, 0), wf = __shfl(xf, 0);
             // running = window (+) running
-            { uint32_t nv = rv, nf = rf; seg_combine(wvv, wf, nv, nf); rv = nv; rf = nf; }
+            { uint32_t nv = rv, nf = rf; seg_combine(wvv, wf, nv, nf, du_cap); rv = nv; rf = nf; }
             if (k < 64) break;
             hi -= 64;
         }
         if (poison) dead = true;
         du_in = rv;                                        // rf set: rv is an absolute index; else a count from the image's first unit (same thing)
         uint32_t iv = agg_v, ifl = agg_f;
-        seg_combine(rv, rf, iv, ifl);
+        seg_combine(rv, rf, iv, ifl, du_cap);
         if (l == 0) op_store(B.wave_desc + w, op_desc(OP_ST_PFX, iv, ifl, dead));
     }
     const uint64_t ts4 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 
     // ---- W: write pass from the true entry states
     const uint32_t prev_p = __shfl_up(S.p_img, 1), prev_cz = __shfl_up(S.cz, 1);
+    const uint32_t prev_v = __shfl_up(v, 1), prev_f = __shfl_up(f, 1);      // inclusive counts of the lane before: this lane's first unit
     PjdDevLaneInfo li;
     li.n_ent = 0; li.seg_first = g.seg_first ? 1u : 0u; li.dc_sum[0] = li.dc_sum[1] = li.dc_sum[2] = 0; li.pad_ = 0;
     if (g.valid && !dead) {
-        const uint32_t D_out = f ? v : du_in + v;
-        uint32_t D = D_out - cnt;
+        // first data unit of this lane = the (saturating) counts before it; not "inclusive - own count": the lane that holds the
+        // picture's last unit also counts whatever follows it, and its inclusive value may have saturated
+        uint32_t D;
+        if (g.seg_first) D = seg_first_du;
+        else if (l == 0) D = du_in;
+        else if (prev_f) D = prev_v;
+        else D = du_in + prev_v < du_cap ? du_in + prev_v : du_cap;
         const uint32_t D_in = D, D_end = seg_first_du + seg_n_du;
         uint32_t p, c, z;
         if (g.seg_first) { p = 0; c = 0; z = 0; }

@@ -50,6 +50,9 @@ void pjd_launch_copy_out(hipStream_t s, const void *src, void *dst_mapped, uint6
 void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, const uint64_t *dense_base, uint32_t n_wg);
 void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b);                                     // lane-stream input
 void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernels: local scan + carry
+// ---- stage-level parity (pjd_k_coefdump.hip): coefficients in the reference's MCU_buffer layout; `out` is zeroed by the caller
+void pjd_launch_coefdump_lanes(hipStream_t s, const PjdDevBatch &b, uint32_t image, uint32_t n_iwg, int16_t *out);
+void pjd_launch_coefdump_dense(hipStream_t s, const PjdDevBatch &b, uint32_t image, const int16_t *scratch, uint32_t first_du, uint32_t n_du, int16_t *out);
 // ---- entropy decode (pjd_k_huffman.hip, pjd_k_huffman_seq.hip) ---------------------
 // exact kernel: image_list[k] decodes into the dense scratch from data unit dense_base[k]
 void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);

@@ -177,6 +177,11 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                 uint32_t code = 0, end10 = 0;
                 for (int len = 1; len <= 16; len++) {            // reference generate_codes (jpeg_scanner.cpp:438-448)
                     const uint32_t cnt = (uint32_t)r.offsets[len] - r.offsets[len - 1];
+                    // bits the cheapest symbol of this length consumes: code + value bits (an out-of-range size stores no value)
+                    for (uint32_t q = r.offsets[len - 1]; q < r.offsets[len] && q < 162; q++) {
+                        const uint32_t sym = r.symbols[q], size = seen_ac[k] ? ((sym & 15u) > 10 ? 0u : (sym & 15u)) : (sym > 11 ? 0u : sym);
+                        if ((uint32_t)len + size < P.min_sym_bits) P.min_sym_bits = (uint32_t)len + size;
+                    }
                     if (code + cnt > (1u << len)) ok = false;
                     if (len == PJD_LUT_BITS) end10 = code + cnt;
                     code = (code + cnt) << 1;
@@ -205,7 +210,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         const bool luma11 = (g.hs == 1 && g.vs == 1);
         const bool std_rule = (d.flags & PJD_F_STANDARD_RESTART) != 0;
         bool sequential = (d.flags & PJD_F_FORCE_SEQUENTIAL) != 0 || !tables_parallel_ok;
-        if (g.n_du >= (1u << 28)) sequential = true;      // look-back descriptors carry 28-bit unit indices
+        if (g.n_du + 1 >= (1u << 28)) sequential = true;  // look-back descriptors carry 28-bit unit indices, saturating at n_du + 1
         uint32_t nseg_total = 1;
         if (RI != 0) {
             nseg_total = (g.n_mcu + RI - 1) / RI;
@@ -343,7 +348,9 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.ecs_buf_bytes = align_up(ecs_off + PJD_SUB_BYTES_MAX + 64, 256);
     P.n_du = du_total;
     P.sub_bytes = sb_max;
-    P.n_ent = (uint64_t)P.subs.size() * PJD_LANE_CAP(sb_max) + 16;
+    if (P.min_sym_bits < 1 || P.tsets.empty()) P.min_sym_bits = 1;
+    P.lane_cap = PJD_LANE_CAP(sb_max, P.min_sym_bits);
+    P.n_ent = (uint64_t)P.subs.size() * P.lane_cap + 16;
     P.n_words = (uint64_t)P.hwaves.size() * PJD_WORD_ROWS(sb_max) * 64;
     P.dense_du = dense_seq;
     P.out_buf_bytes = align_up(out_off, 256);

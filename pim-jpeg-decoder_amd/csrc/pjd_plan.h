@@ -16,6 +16,8 @@ struct PjdHostImage {
 struct PjdPlan {
     int out_format = 0;
     uint32_t sub_bytes = 512;              // Huffman subsequence size chosen for this batch
+    uint32_t min_sym_bits = 16;            // fewest bits any Huffman symbol of the batch's tables consumes (code + value bits)
+    uint32_t lane_cap = 0;                 // entries per lane region: PJD_LANE_CAP(sub_bytes, min_sym_bits)
     std::vector<PjdDevImage> images;
     std::vector<PjdHostImage> host;
     std::vector<PjdDevTset> tsets;         // table sets: images with identical Huffman tables share one

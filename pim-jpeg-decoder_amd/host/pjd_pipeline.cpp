@@ -135,7 +135,8 @@ struct Pipe {
     std::vector<Input> in;
     std::vector<std::unique_ptr<Job>> jobs;
     std::atomic<int> next_input{0};
-    std::vector<int> devs;               // HIP ordinals in use
+    std::vector<int> devs;               // HIP ordinals in use (after run() opened them: the ones that opened)
+    std::vector<int> entry_of;           // per device in use: its index in the caller's `devices` list (statistics are reported per entry)
     std::vector<std::unique_ptr<Queue<int>>> ready;   // per device: job indices whose inputs are all scanned
     Queue<SinkTask> sinkq;
     std::mutex stat_m, latch_m;
@@ -275,7 +276,7 @@ struct Pipe {
             st.n_decoded += decoded; st.n_rejected += rejected;
             st.pixels += pixels; st.ecs_bytes += ecs; st.out_bytes += outb;
             st.n_exact_images += exact;
-            st.device_batches[d]++; st.device_in_bytes[d] += job.cost; st.n_stolen += stolen ? 1 : 0;
+            st.device_batches[entry_of[d]]++; st.device_in_bytes[entry_of[d]] += job.cost; st.n_stolen += stolen ? 1 : 0;   // per entry of opts.devices
         }
         park_slot(res);
         if (trace) std::fprintf(stderr, "[pjdpipe] slot of dev %d leaves %.2f\n", devs[d], (now_s() - t_run0) * 1e3);
@@ -320,20 +321,22 @@ struct Pipe {
         std::vector<std::vector<SlotRes>> res;
         {
             std::vector<int> live;
-            for (int dev : devs) {
+            for (size_t di = 0; di < devs.size(); di++) {
+                const int dev = devs[di];
                 std::vector<SlotRes> r;
                 for (int k = 0; k < o.slots; k++) {
                     SlotRes s = take_slot(dev);
                     if (!s.ctx) { park_slot(s); break; }
                     r.push_back(s);
                 }
-                if (!r.empty()) { live.push_back(dev); res.push_back(std::move(r)); }
+                if (!r.empty()) { live.push_back(dev); entry_of.push_back((int)di); res.push_back(std::move(r)); }
             }
             if (live.empty()) {                            // no device: one slot without a context reports every batch as failed
                 SlotRes none;
                 none.device = devs[0];
                 res.push_back(std::vector<SlotRes>(1, none));
                 live.push_back(devs[0]);
+                entry_of.push_back(0);
             } else {
                 for (const std::vector<SlotRes> &r : res) slots_open.fetch_add((int)r.size());
                 st.n_devices = live.size();

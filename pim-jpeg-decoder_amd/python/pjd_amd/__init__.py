@@ -18,6 +18,7 @@ LIBPIPE = os.path.join(LIB_DIR, "libpjdpipe.so")
 OUT_RGB8, OUT_BMP = 0, 1
 F_STANDARD_RESTART, F_FORCE_SEQUENTIAL, F_STANDARD_ZIGZAG = 1, 2, 4
 MAX_KERNELS = 16
+ABI_VERSION = 3          # PJD_VERSION of include/pjd.h these ctypes structs mirror
 
 
 class HuffTable(C.Structure):
@@ -103,6 +104,8 @@ def dev_lib():
         L = C.CDLL(LIBPJD)
         vp, i32 = C.c_void_p, C.c_int
         L.pjd_version.restype = i32
+        if L.pjd_version() != ABI_VERSION:
+            raise PjdError(f"{LIBPJD} has ABI version {L.pjd_version()}, these bindings mirror version {ABI_VERSION}: rebuild")
         L.pjd_open.restype = i32
         L.pjd_open.argtypes = [i32, C.POINTER(vp)]
         L.pjd_close.argtypes = [vp]
@@ -145,6 +148,10 @@ def dev_lib():
         L.pjd_exec_dpu_payload.argtypes = [vp, vp, vp, i32]
         L.pjd_output_size.restype = C.c_uint64
         L.pjd_output_size.argtypes = [C.c_uint32, C.c_uint32, i32]
+        L.pjd_coefficients_size.restype = C.c_uint64
+        L.pjd_coefficients_size.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8]
+        L.pjd_batch_download_coefficients.restype = i32
+        L.pjd_batch_download_coefficients.argtypes = [vp, i32, vp, C.c_uint64]
         L.pjd_plan_info.restype = i32
         L.pjd_plan_info.argtypes = [C.POINTER(ImageDesc), i32, i32, C.POINTER(BatchInfo)]
         _dev = L
@@ -309,6 +316,15 @@ class Batch:
             outs = [o.reshape(int(self._descs[i].height), int(self._descs[i].width), 3) for i, o in enumerate(outs)]
         return outs, [int(st[i]) for i in range(self.n)]
 
+
+    def coefficients(self, i):
+        """Stage-level parity: image i's coefficients after entropy decoding, in the reference's MCU_buffer layout
+        (n_dpus x 19200 int16, reference src/jpeg_scanner.cpp:733-741)."""
+        d = self._descs[i]
+        n = int(self.L.pjd_coefficients_size(d.width, d.height, d.h_samp, d.v_samp))
+        out = np.zeros(n, np.int16)
+        self.ctx._check(self.L.pjd_batch_download_coefficients(self._h, i, out.ctypes.data, n), "pjd_batch_download_coefficients")
+        return out.reshape(-1, 19200)
 
     def download_packed(self):
         """All pictures in one D2H copy into page-locked memory; returns (list of arrays, statuses)."""

@@ -64,6 +64,48 @@ def sos_end(data):
     return i + 2 + ((data[i + 2] << 8) | data[i + 3])
 
 
+def rewrite_dqt(d, value_of, precision16=True):
+    """Rewrite every DQT segment of `d`: entry k (zigzag order) of table `tid` becomes value_of(tid, k, old), written as a
+    16-bit (precision 1) or 8-bit table."""
+    out = bytearray(d[:2])
+    p = 2
+    while True:
+        assert d[p] == 0xFF
+        m = d[p + 1]
+        ln = (d[p + 2] << 8) | d[p + 3]
+        if m == 0xDB:
+            body = d[p + 4:p + 2 + ln]
+            new = bytearray()
+            q = 0
+            while q < len(body):
+                assert body[q] >> 4 == 0
+                tid = body[q] & 15
+                new.append((0x10 if precision16 else 0x00) | tid)
+                for k, v in enumerate(body[q + 1:q + 65]):
+                    nv = int(value_of(tid, k, v))
+                    new += bytes([nv >> 8, nv & 255]) if precision16 else bytes([nv & 255])
+                q += 65
+            out += bytes([0xFF, 0xDB, (len(new) + 2) >> 8, (len(new) + 2) & 255]) + new
+        else:
+            out += d[p:p + 2 + ln]
+        p += 2 + ln
+        if m == 0xDA:
+            break
+    out += d[p:]
+    return bytes(out)
+
+
+def relabel_h1v2(d):
+    """A 4:2:2 (h2v1) stream with swapped dimensions is a valid 4:4:0 (h1v2) stream (Pillow cannot emit that mode)."""
+    d = bytearray(d)
+    i = find_marker(d, 0xC0)
+    hh, ww = (d[i + 5] << 8) | d[i + 6], (d[i + 7] << 8) | d[i + 8]
+    d[i + 5:i + 9] = bytes([ww >> 8, ww & 255, hh >> 8, hh & 255])
+    assert d[i + 11] == 0x21
+    d[i + 11] = 0x12
+    return bytes(d)
+
+
 def build_set():
     S = {}
     # --- the parity envelope (SURVEY section 0.7) ---------------------------------
@@ -137,6 +179,26 @@ def build_set():
             break
     out += d[p:]
     S["dqt16_64x48_444"] = bytes(out)
+
+    # --- int16 wrap through the WHOLE path (round 3): saturated noise at q100 (coefficients up to +-1000) with the quantisation
+    #     tables replaced by huge entries, so that (int16)(coef * Q) wraps in dequantisation (reference src/decoder_dpu.c:169-172),
+    #     both IDCT passes store wrapped int16 (:218-320) and |Cb|, |Cr| leave the range where the colour products fit 32 bits
+    #     (:376-382).  All four sampling modes + grey; 16-bit tables with 65535 / 40000 / mixed entries and 8-bit tables of 255.
+    wrap_q = {"q65535": (True, lambda t, k, v: 65535), "q40000": (True, lambda t, k, v: 40000 if (k + t) % 3 else 65535 - 7 * k),
+              "q255": (False, lambda t, k, v: 255)}
+    wk = 0
+    for tag, sub in [("444", 0), ("422", 1), ("420", 2), ("440", 1), ("gray", None)]:
+        for qn, (p16, fn) in wrap_q.items():
+            wk += 1
+            w, h = (88, 56) if tag != "440" else (56, 88)
+            img = picture(w, h, 300 + wk, "noise")
+            if sub is None:
+                d = enc(img.convert("L"), quality=100)
+            else:
+                d = enc(img, quality=100, subsampling=sub)
+            if tag == "440":
+                d = relabel_h1v2(d)
+            S[f"wrap_{tag}_{qn}"] = rewrite_dqt(d, fn, p16)
 
     # --- negative / divergent cases ---------------------------------------------
     S["neg_progressive_64x48"] = enc(picture(64, 48, 50), quality=85, progressive=True)
@@ -230,9 +292,14 @@ def main():
     with open(REFERENCE_SAMPLE, "rb") as f:
         S["ilsvrc_val_00000001"] = f.read()     # the reference's bundled sample (data, 109,527 B)
 
+    # files already committed are kept byte for byte (encoder output varies between libjpeg builds); only new names are written
     for fn in os.listdir(HERE):
-        if fn.endswith(".jpg"):
+        if fn.endswith(".jpg") and fn[:-4] not in S:
             os.remove(os.path.join(HERE, fn))
+    for name in sorted(S):
+        fp = os.path.join(HERE, name + ".jpg")
+        if os.path.exists(fp):
+            S[name] = open(fp, "rb").read()
     manifest = {}
     tmp = tempfile.mkdtemp()
     try:

@@ -496,6 +496,10 @@ def test_pipeline_devices_list_of_one_equals_single_device(tmp_path):
     st = pjd_amd.pipe_run(jpegs=jpegs, batch_images=3, slots=2, devices=[0])
     assert st["n_devices"] == 1 and st["device_batches"][0] == st["n_batches"] == 6 and st["n_stolen"] == 0
     assert st["device_in_bytes"][0] == sum(len(j) for j in jpegs)
+    # statistics are per entry of the list, also when an earlier entry did not open
+    st = pjd_amd.pipe_run(jpegs=jpegs, batch_images=3, slots=2, devices=[97, 0])
+    assert st["n_devices"] == 1 and st["device_batches"][0] == 0 and st["device_batches"][1] == st["n_batches"] == 6
+    assert st["device_in_bytes"][0] == 0 and st["device_in_bytes"][1] == sum(len(j) for j in jpegs)
     with pytest.raises(pjd_amd.PjdError):
         pjd_amd.pipe_run(jpegs=jpegs, devices=[0, 0])
     p = subprocess.run([os.path.join(ROOT, "bin", "decoder"), "--devices", "zero", str(tmp_path / "one" / (names[0] + ".jpg"))], capture_output=True, text=True)
@@ -665,3 +669,147 @@ def test_two_batches_in_flight_on_two_contexts(port):
     finally:
         for c in ctxs:
             c.close()
+
+
+# ---- stage-level parity: the entropy decoder alone, against the reference's own decode_Huffman_data -----------------------------
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_coefficients_match_reference_hashes(ctx, mode):
+    """SURVEY section 4 'stage-level dumps: coef after Huffman'.  manifest.json's coef_sha256 is the sha256 of the reference's
+    MCU_buffer after ITS decode_Huffman_data (src/jpeg_scanner.cpp:707-756, run by oracle/_ref when the fixtures were made).
+    pjd_batch_download_coefficients lays the GPU decoder's output (lane streams of the parallel kernel / dense scratch of the
+    exact kernel) out the same way; the hashes must be equal for every decodable fixture -- no restated code in between, no
+    clamps that could hide a wrong coefficient."""
+    import pjd_amd
+    flags = pjd_amd.F_FORCE_SEQUENTIAL if mode == "exact" else 0
+    scanned = [_desc(n, flags) for n in VALID]
+    with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8) as b:
+        b.upload(); b.decode(); b.sync()
+        info = b.info()
+        bad = []
+        for i, name in enumerate(VALID):
+            got = hashlib.sha256(b.coefficients(i).tobytes()).hexdigest()
+            if got != MANIFEST[name]["coef_sha256"]:
+                bad.append(name)
+        assert not bad, bad
+    if mode == "fast":      # most of them really came out of the lane streams
+        assert info["n_sequential"] + info["n_fallback"] < len(VALID) // 4
+
+
+def test_coefficients_of_a_big_batch_member_match_oracle(ctx, port):
+    """The same check away from the fixtures: pictures inside a mixed batch (dense optimised-table streams, restart intervals,
+    every sampling mode) against the oracle port's coefficient buffer (pinned to the reference's on all fixtures, test_oracle.py)."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = synth.cfg3_imagenet_like(24, seed=11, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    jpegs += [synth.make(333, 200, 7, 97, synth.SUB_420, 0, synth.DENSE_DETAIL, True), synth.make(160, 120, 8, 95, synth.SUB_444, 5),
+              synth.make(201, 77, 9, 50, synth.SUB_422, 0), synth.make(64, 200, 10, 90, synth.SUB_440, 0), synth.make(99, 99, 11, 75, synth.SUB_GREY, 4)]
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    with ctx.batch([s.desc for s in scanned]) as b:
+        b.upload(); b.decode(); b.sync()
+        for i, j in enumerate(jpegs):
+            want = port.decode(j)["coef"]
+            got = b.coefficients(i)
+            assert got.shape == want.shape and np.array_equal(got, want), i
+
+
+# ---- BASELINE config 4 at its per-GPU size ----------------------------------------------------------------------------------------
+def test_config4_per_gpu_batch_of_8192(ctx, port):
+    """BASELINE config 4 = 65,536 pictures sharded 8 ways: 8,192 per GPU, no collective.  One rank's share in ONE batch, pictures
+    of the default benchmark distribution (cfg3): nothing leaves the parallel path, decoding twice gives the same bytes, and a
+    256-picture sample (every 32nd) equals the oracle."""
+    import pjd_amd
+    synth = _synth()
+    n = 8192
+    jpegs = synth.cfg3_imagenet_like(n, seed=4, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    assert all(s.valid for s in scanned)
+    with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_BMP) as b:
+        b.upload(); b.decode()
+        outs, st = b.download_packed()
+        info = b.info()
+        h1 = hashlib.sha256(b"".join(o.tobytes() for o in outs)).hexdigest()
+        b.decode()
+        outs2, st2 = b.download_packed()
+        h2 = hashlib.sha256(b"".join(o.tobytes() for o in outs2)).hexdigest()
+    assert st == [0] * n and st2 == st and h1 == h2
+    assert info["n_images"] == n and info["n_sequential"] == 0 and info["n_fallback"] == 0 and sum(info["flag_waves"]) == 0
+    sample = list(range(0, n, 32))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        same = list(ex.map(lambda i: outs[i].tobytes() == port.decode(jpegs[i])["bmp"], sample))
+    assert all(same), [sample[k] for k, ok in enumerate(same) if not ok][:10]
+
+
+# ---- the multi-rank rehearsal shape (round-2 incident, DESIGN 5a) --------------------------------------------------------------
+def test_shard_batch_and_empty_batch_replayed_keep_their_state(ctx, port):
+    """The shape on which a replayed 128-byte runtime memset node once left non-zero words in the statistics buffer: a batch that
+    holds one SHARD of a picture and an EMPTY batch (a rank beyond the number of restart segments), both captured as graphs and
+    replayed alternately.  Every replay must report the same statistics, the same entry count and no flagged wave; the
+    per-decode state is reset by pjd_k_reset (csrc/pjd_k_backend.hip), not by runtime memset nodes."""
+    import pjd_amd
+    from pjd_amd import parallel
+    name = "rstrow_200x150_444_opt"
+    s = _desc(name)
+    segs, ecs = s.seg_offsets(), s.ecs()
+    f, c = parallel.segment_range(len(segs), 1, 3)
+    lo, hi = int(segs[f]), int(segs[f + c]) if f + c < len(segs) else len(ecs)
+    d, keep = parallel.shard_descriptor(s.desc, segs, ecs[lo:hi], lo, 1, 3)
+    want = port.decode(golden_bytes(name))["rgb"]
+    c2 = pjd_amd.Context(0)
+    try:
+        with ctx.batch([d]) as shard, c2.batch([]) as empty:
+            for b in (shard, empty):
+                b.upload(); b.capture()
+            seen = []
+            for _ in range(6):
+                shard.decode(); empty.decode()
+                shard.sync(); empty.sync()
+                i, e = shard.info(), empty.info()
+                seen.append((i["n_entries"], i["sync_rounds"], i["sync_lane_passes"], i["fix_rounds"], tuple(i["flag_waves"])))
+                assert e["n_entries"] == 0 and sum(e["flag_waves"]) == 0 and e["sync_rounds"] == 0
+            assert len(set(seen)) == 1 and sum(seen[0][4]) == 0 and seen[0][0] > 0, seen
+            outs, st = shard.download()
+            assert st == [0]
+            rows = slice(f * 8, min((f + c) * 8, want.shape[0]))
+            assert np.array_equal(outs[0][rows], want[rows])
+    finally:
+        c2.close()
+
+
+def _handmade_grey_with_tail(tail_bytes):
+    """A 16x16 grey baseline JPEG built by hand: DC table {'0': size 0, '10': size 1}, AC table {'0': EOB}; four data units with
+    DC differences +1, 0, -1, +1; then `tail_bytes` zero bytes of entropy-coded data after the last unit (each zero BIT pair
+    decodes as one more unit: a 1-bit DC code and a 1-bit EOB), then EOI."""
+    def seg(marker, body):
+        return bytes([0xFF, marker, (len(body) + 2) >> 8, (len(body) + 2) & 255]) + body
+    dqt = seg(0xDB, bytes([0]) + bytes([16] * 64))
+    sof = seg(0xC0, bytes([8, 0, 16, 0, 16, 1, 1, 0x11, 0]))
+    dht_dc = seg(0xC4, bytes([0x00, 1, 1] + [0] * 14 + [0, 1]))
+    dht_ac = seg(0xC4, bytes([0x10, 1] + [0] * 15 + [0x00]))
+    sos = seg(0xDA, bytes([1, 1, 0x00, 0, 63, 0]))
+    bits = "10" "1" "0" + "0" "0" + "10" "0" "0" + "10" "1" "0"      # (DC code, value bits, EOB) x 4
+    bits += "0" * (-len(bits) % 8)
+    ecs = bytes(int(bits[k:k + 8], 2) for k in range(0, len(bits), 8))
+    return b"\xff\xd8" + dqt + sof + dht_dc + dht_ac + sos + ecs + bytes(tail_bytes) + b"\xff\xd9"
+
+
+@pytest.mark.parametrize("tail_mib", [0, 1, 65])
+def test_long_tail_after_the_last_unit_is_ignored(ctx, port, tail_mib):
+    """Bytes after the picture's last data unit are never decoded by the reference (its loops end with the MCU grid,
+    src/jpeg_scanner.cpp:721-722).  The parallel decoder's speculative lanes do count units in such a tail; with a 1-bit DC
+    code and a 1-bit EOB, 64 MiB of it hold 2^28 units -- the width of a look-back descriptor -- so the counts saturate
+    (pjd_k_huffman.hip: seg_combine) instead of wrapping back into the picture's range."""
+    import pjd_amd
+    data = _handmade_grey_with_tail(tail_mib << 20)
+    s = pjd_amd.Scanned(data)
+    assert s.valid
+    want = port.decode(data)
+    assert want["huff_rc"] == 0
+    with ctx.batch([s.desc]) as b:
+        b.upload(); b.decode()
+        outs, st = b.download()
+        coef = b.coefficients(0)
+    assert st == [0]
+    assert np.array_equal(outs[0], want["rgb"])
+    assert np.array_equal(coef, want["coef"])
+    assert len(set(want["rgb"].reshape(-1).tolist())) > 1        # the four units differ: garbage written over them would show

@@ -95,7 +95,7 @@ def test_libpjd_exports_every_declared_symbol():
     missing = [n for n in names if n not in exp]
     assert not missing, missing
     L = pjd_amd.dev_lib()          # loads (no compute call)
-    assert L.pjd_version() == 1
+    assert L.pjd_version() == pjd_amd.ABI_VERSION
     assert L.pjd_output_size(500, 375, pjd_amd.OUT_BMP) == 562526
     assert L.pjd_output_size(61, 45, pjd_amd.OUT_BMP) == 26 + 45 * (183 + 1)
 

@@ -84,3 +84,36 @@ def test_stage_entry_points_compose(port):
     for s in range(3):
         port.dpu_stage(meta, b, s)
     assert np.array_equal(a, b)
+
+
+WRAP = [n for n in NAMES if n.startswith("wrap_")]
+
+
+@pytest.mark.parametrize("name", WRAP)
+def test_wrap_fixtures_do_wrap(port, name):
+    """The wrap_* fixtures exist to push int16 truncation and 32-bit product overflow through the whole path (reference
+    src/decoder_dpu.c:169-172 dequantise, :218-320 IDCT stores, :376-382 colour products).  Check on the oracle's own stage
+    outputs that each one does what it claims: products beyond int16 in the dequantiser, IDCT outputs using the full int16
+    range, and (colour pictures) chroma samples far outside +-365 / +-288, where 5880414 * Cr and 7432306 * Cb leave 32 bits."""
+    o = port.decode(golden_bytes(name))
+    assert o["valid"] and o["huff_rc"] == 0
+    meta, coef = o["metadata"], o["coef"].astype(np.int64)
+    ncomp = int(meta[4])
+    wrapped = 0
+    blocks = coef.reshape(-1, 3, 4, 64)                       # [blk16][component][position][natural index]
+    for c in range(ncomp):
+        q = meta[20 + 64 * int(meta[7 + c]):][:64].astype(np.int64)
+        prod = blocks[:, c] * q
+        wrapped += int((np.abs(prod) > 32767).sum())
+    assert wrapped > 300, wrapped
+    if name.endswith("q65535"):
+        return                    # coef * 65535 = -coef modulo 2^16: the truncation fires on every product, the values stay small
+    st = o["coef"].copy()
+    for d in range(st.shape[0]):
+        port.dpu_stage(meta, st[d], 0)
+        port.dpu_stage(meta, st[d], 1)
+    after_idct = st.reshape(-1, 3, 4, 64)
+    assert int(np.abs(after_idct[:, 0].astype(np.int32)).max()) > 20000            # int16 stores of the IDCT passes are exercised
+    if ncomp == 3:
+        assert int((np.abs(after_idct[:, 2].astype(np.int32)) > 365).sum()) > 100   # Cr: 5880414 * Cr overflows int32
+        assert int((np.abs(after_idct[:, 1].astype(np.int32)) > 288).sum()) > 100   # Cb: 7432306 * Cb overflows int32
