@@ -14,6 +14,7 @@
  *   exec()                    decoder_host.cpp:292      pjd_batch_decode (+ _sync)
  *   copy(batch.mcus,"mcus")   decoder_host.cpp:308      pjd_batch_download
  *   4 x dpus()[0]->copy(ctr)  decoder_host.cpp:309-312  pjd_batch_decode_timed
+ *   one picture over all DPUs decoder_host.cpp:125-149   pjd_split_decode (restart segments over GPUs)
  *   the per-DPU payload T0    decoder_dpu.c:57-58       pjd_exec_dpu_payload (literal)
  *
  * Plain pointers and sizes only; no C++ or torch types.  Thread model: one
@@ -203,6 +204,37 @@ int  pjd_batch_download_coefficients(pjd_batch *b, int image, int16_t *out, uint
 /* One call: create + upload + decode + download + destroy.                    */
 int  pjd_decode_batch(pjd_ctx *ctx, const pjd_image_desc *images, int n_images,
                       int out_format, uint8_t *const *out, int32_t *status);
+
+/* ---- one picture over several devices (BASELINE config 5) -------------------------------------- *
+ * Replaces what the reference does with every picture -- spread it over all allocated DPUs, copy the metadata
+ * to each and collect the samples (decoder_host.cpp:125-149,225,262-312) -- for a picture with restart
+ * intervals: device k of `devices` decodes a contiguous range of restart segments (pjd_split_plan), the
+ * descriptor (tables + segment offsets, ~20 KB) is broadcast from the first device's HBM with one
+ * ncclBroadcast (RCCL over xGMI; loaded on first use; plain copies if RCCL is missing), every device
+ * uploads only its slice of `desc->ecs`, and the rows come back into `out` (pjd_output_size bytes).
+ * One host thread per device inside the call.  A picture that cannot be split (no DRI; subsampled luma
+ * under the reference's restart rule) is decoded by devices[0] alone; so is, a second time, a picture whose
+ * entropy decode reports an error, so that status and partial picture are the reference's.               */
+#define PJD_SPLIT_MAX_DEVICES 16
+typedef struct pjd_split_stats {
+    double   wall_s, broadcast_s, upload_s, exec_s, download_s;   /* the three stages: slowest rank          */
+    uint64_t blob_bytes;               /* size of the broadcast descriptor                                  */
+    uint64_t ecs_bytes[PJD_SPLIT_MAX_DEVICES];   /* entropy-coded bytes each rank uploaded                  */
+    uint32_t n_segments, n_ranks;      /* restart segments of the picture; ranks that had work              */
+    uint32_t n_exact;                  /* shards the exact one-lane kernel decoded                          */
+    int32_t  rccl_used;                /* 1: the descriptor travelled by ncclBroadcast                      */
+    int32_t  redone_whole;             /* 1: decoded again on one device after an entropy-coding error      */
+} pjd_split_stats;
+int  pjd_split_decode(const pjd_image_desc *desc, const int32_t *devices, int n_devices, int out_format,
+                      uint8_t *out, uint64_t capacity, int32_t *status, pjd_split_stats *stats);
+/* The range arithmetic on its own (no device needed): rank `rank` of `world` takes segments
+ * [shard_first_seg, +shard_n_segs) = bytes [*byte_lo, *byte_hi) of desc->ecs = MCUs [*first_mcu, *last_mcu).
+ * `shard` (optional, with `seg_scratch`: desc->n_segments words that must outlive it) becomes the descriptor
+ * that rank passes to pjd_batch_create: its ecs points at the slice, its offsets are relative to the slice.
+ * Returns PJD_OK, 1 if the rank has no segment (more ranks than segments), PJD_E_ARG.                      */
+int  pjd_split_plan(const pjd_image_desc *desc, int world, int rank, pjd_image_desc *shard, uint64_t *seg_scratch,
+                    uint64_t *byte_lo, uint64_t *byte_hi, uint32_t *first_mcu, uint32_t *last_mcu);
+void pjd_split_release(void);          /* drops the cached RCCL communicators                               */
 
 /* ---- the literal DPU contract ---------------------------------------------- *
  * metadata: n_dpus x u32[276]   (decoder_host.cpp:156-178 index map)

@@ -16,6 +16,8 @@
 // include/pjd_pipeline.h (scan, copies, kernels and BMP writes overlap; messages are printed in input
 // order at the end instead of interleaved).  --devices spreads the batches over several GPUs of the node,
 // as the reference spreads pictures over all allocated DPUs (:225); it implies --pipeline.
+// --split [--devices 0,1,...]: every picture is decoded by all listed devices TOGETHER (pjd_split_decode): restart-segment ranges per
+// device, the descriptor broadcast with RCCL, rows assembled on the host -- for single pictures larger than one device's share.
 #include <sys/stat.h>
 #include <time.h>
 
@@ -103,11 +105,63 @@ static int run_pipeline(const std::vector<std::string> &files, const std::vector
     return 0;
 }
 
+// ---- --split mode: every picture is decoded by ALL listed devices together (pjd_split_decode) -------------------------------
+// For pictures larger than one device's share: the reference spreads every picture over all its DPUs (decoder_host.cpp:125-149,
+// 225); here a picture with restart intervals is cut into restart-segment ranges, one per device, the descriptor is broadcast
+// with RCCL and the rows are assembled on the host.  Pictures that cannot be cut are decoded by the first device.
+static int run_split(const std::vector<std::string> &files, const std::vector<int32_t> &devices)
+{
+    double t_total = now_s(), t_scan = 0, t_bc = 0, t_up = 0, t_exec = 0, t_down = 0, t_bmp = 0;
+    int calls = 0, rccl_calls = 0;
+    bool announced = false;
+    for (const std::string &f : files) {
+        double t0 = now_s();
+        pjd_scanned *s = nullptr;
+        const int sr = pjd_scan_file(f.c_str(), &s);
+        t_scan += now_s() - t0;
+        if (sr == 2) { std::cout << f << ": Error - Error opening input file\n" << f << ": Error - Invalid JPEG\n"; continue; }
+        std::cout << pjd_scanned_log(s);
+        if (sr != 0) { pjd_scanned_free(s); continue; }
+        const pjd_image_desc *d = pjd_scanned_desc(s);
+        std::vector<uint8_t> out(pjd_output_size(d->width, d->height, PJD_OUT_BMP));
+        int32_t status = 0;
+        pjd_split_stats st;
+        const int rc = pjd_split_decode(d, devices.data(), (int)devices.size(), PJD_OUT_BMP, out.data(), out.size(), &status, &st);
+        if (rc == PJD_E_NODEVICE) { std::cout << "Error - no usable MI355X (gfx950) device (pjd_open returned " << rc << ")\n"; pjd_scanned_free(s); return 2; }
+        if (rc == PJD_E_ARG && !announced) { std::cout << "Error - Invalid arguments\n"; pjd_scanned_free(s); return 1; }
+        if (!announced) { std::cout << devices.size() << " MI355X devices are allocated (one picture is split over " << devices.size() << " devices)\n"; announced = true; }
+        if (rc != PJD_OK) { std::cout << f << ": Error - GPU decode failed (" << rc << ")\n"; pjd_scanned_free(s); continue; }
+        calls++; rccl_calls += st.rccl_used;
+        t_bc += st.broadcast_s; t_up += st.upload_s; t_exec += st.exec_s; t_down += st.download_s;
+        if (status != PJD_ST_OK) std::cout << f << ": " << pjd_status_string(status) << "\n";
+        std::cout << f << ": " << st.n_segments << " restart segments, split over " << st.n_ranks << " devices"
+                  << (st.rccl_used ? ", descriptor broadcast by RCCL" : "") << (st.redone_whole ? ", decoded again on one device" : "") << "\n";
+        t0 = now_s();
+        const std::string o = bmp_name(f);
+        if (pjd_write_file(o.c_str(), out.data(), out.size()) != 0) std::cout << o << ": Error - Unable to create BMP file" << std::endl;
+        t_bmp += now_s() - t0;
+        pjd_scanned_free(s);
+    }
+    pjd_split_release();
+    t_total = now_s() - t_total;
+    std::cout << "\nProfiles:\n";
+    std::cout << "End-to-end execution time: " << t_total << "s\n";
+    std::cout << "MCU Offloader execution time (total; per picture the slowest device counts): \n";
+    std::cout << " - JPEG scan time: " << t_scan << "s\n";
+    std::cout << " - descriptor broadcast time: " << t_bc << "s (" << rccl_calls << " by RCCL)\n";
+    std::cout << " - CPU-to-GPU transfer time: " << t_up << "s\n";
+    std::cout << " - GPU execution time: " << t_exec << "s\n";
+    std::cout << " - GPU-to-CPU transfer time: " << t_down << "s\n";
+    std::cout << " - BMP write time: " << t_bmp << "s\n";
+    std::cout << " - Total " << calls << " calls\n";
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int device = 0;
     size_t batch_images = 1024;
-    bool pipeline = false;
+    bool pipeline = false, split = false;
     int slots = 0, scan_threads = 0, write_threads = 0;
     std::vector<std::string> files;
     std::vector<int32_t> devices;
@@ -125,6 +179,7 @@ int main(int argc, char **argv)
         }
         else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch_images = (size_t)std::atoll(argv[++i]);
         else if (!std::strcmp(argv[i], "--pipeline")) pipeline = true;
+        else if (!std::strcmp(argv[i], "--split")) split = true;
         else if (!std::strcmp(argv[i], "--slots") && i + 1 < argc) slots = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--scan-threads") && i + 1 < argc) scan_threads = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--write-threads") && i + 1 < argc) write_threads = std::atoi(argv[++i]);
@@ -141,6 +196,13 @@ int main(int argc, char **argv)
         sized.emplace_back(stat(f.c_str(), &st) == 0 ? (long long)st.st_size : 0LL, f);
     }
     std::stable_sort(sized.begin(), sized.end(), [](const std::pair<long long, std::string> &a, const std::pair<long long, std::string> &b) { return a.first < b.first; });
+    if (split) {
+        std::vector<std::string> ordered;
+        for (const auto &p : sized) ordered.push_back(p.second);
+        if (devices.empty()) devices.push_back(device);
+        for (int32_t d : devices) if (d < 0) { std::cout << "Error - Invalid arguments\n"; return 1; }
+        return run_split(ordered, devices);
+    }
     if (pipeline) {
         std::vector<std::string> ordered;
         for (const auto &p : sized) ordered.push_back(p.second);

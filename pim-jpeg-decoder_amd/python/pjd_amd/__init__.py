@@ -62,6 +62,19 @@ class BatchInfo(C.Structure):
                 ("n_entries", C.c_uint64), ("flag_waves", C.c_uint64 * 8)]
 
 
+SPLIT_MAX_DEVICES = 16
+
+
+class SplitStats(C.Structure):
+    _fields_ = [("wall_s", C.c_double), ("broadcast_s", C.c_double), ("upload_s", C.c_double), ("exec_s", C.c_double), ("download_s", C.c_double),
+                ("blob_bytes", C.c_uint64), ("ecs_bytes", C.c_uint64 * SPLIT_MAX_DEVICES),
+                ("n_segments", C.c_uint32), ("n_ranks", C.c_uint32), ("n_exact", C.c_uint32),
+                ("rccl_used", C.c_int32), ("redone_whole", C.c_int32)]
+
+    def as_dict(self):
+        return {k: (list(getattr(self, k)) if k == "ecs_bytes" else getattr(self, k)) for k, _ in self._fields_}
+
+
 class PjdError(RuntimeError):
     pass
 
@@ -152,6 +165,12 @@ def dev_lib():
         L.pjd_coefficients_size.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8]
         L.pjd_batch_download_coefficients.restype = i32
         L.pjd_batch_download_coefficients.argtypes = [vp, i32, vp, C.c_uint64]
+        L.pjd_split_decode.restype = i32
+        L.pjd_split_decode.argtypes = [C.POINTER(ImageDesc), C.POINTER(C.c_int32), i32, i32, vp, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(SplitStats)]
+        L.pjd_split_plan.restype = i32
+        L.pjd_split_plan.argtypes = [C.POINTER(ImageDesc), i32, i32, C.POINTER(ImageDesc), vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pjd_split_release.restype = None
         L.pjd_plan_info.restype = i32
         L.pjd_plan_info.argtypes = [C.POINTER(ImageDesc), i32, i32, C.POINTER(BatchInfo)]
         _dev = L
@@ -447,6 +466,39 @@ def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_image
     if rc != 0:
         raise PjdError(f"pipeline failed ({rc})")
     return st.as_dict()
+
+
+def split_decode(desc, devices, out_format=OUT_RGB8):
+    """pjd_split_decode: ONE picture over several devices (restart-segment ranges, RCCL broadcast of the descriptor).
+    -> (picture as np.uint8 array, status, stats dict)."""
+    L = dev_lib()
+    n = int(L.pjd_output_size(desc.width, desc.height, out_format))
+    out = np.zeros(n, np.uint8)
+    dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    st, status = SplitStats(), C.c_int32(0)
+    rc = L.pjd_split_decode(C.byref(desc), dv, len(devices), out_format, out.ctypes.data, n, C.byref(status), C.byref(st))
+    if rc != 0:
+        raise PjdError(f"pjd_split_decode failed ({rc})")
+    if out_format == OUT_RGB8:
+        out = out.reshape(int(desc.height), int(desc.width), 3)
+    return out, int(status.value), st.as_dict()
+
+
+def split_plan(desc, world, rank):
+    """pjd_split_plan (host only) -> None if the rank has no segment, else dict(first_seg, n_segs, byte_lo, byte_hi, first_mcu, last_mcu,
+    seg_offsets of the shard descriptor, ecs_len of the shard)."""
+    L = dev_lib()
+    shard = ImageDesc()
+    scratch = np.zeros(max(int(desc.n_segments), 1), np.uint64)
+    lo, hi, m0, m1 = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+    rc = L.pjd_split_plan(C.byref(desc), world, rank, C.byref(shard), scratch.ctypes.data, C.byref(lo), C.byref(hi), C.byref(m0), C.byref(m1))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise PjdError(f"pjd_split_plan failed ({rc})")
+    return {"first_seg": int(shard.shard_first_seg), "n_segs": int(shard.shard_n_segs), "byte_lo": lo.value, "byte_hi": hi.value,
+            "first_mcu": m0.value, "last_mcu": m1.value, "seg_offsets": scratch.copy(), "ecs_len": int(shard.ecs_len),
+            "ecs_delta": (int(shard.ecs or 0) - int(desc.ecs or 0))}
 
 
 def plan_info(descs, out_format=OUT_RGB8):

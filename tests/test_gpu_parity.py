@@ -813,3 +813,102 @@ def test_long_tail_after_the_last_unit_is_ignored(ctx, port, tail_mib):
     assert np.array_equal(outs[0], want["rgb"])
     assert np.array_equal(coef, want["coef"])
     assert len(set(want["rgb"].reshape(-1).tolist())) > 1        # the four units differ: garbage written over them would show
+
+
+# ---- ONE picture over several devices, in C++ behind the ABI (pjd_split_decode, BASELINE config 5) ------------------------------
+def _split_cases():
+    synth = _synth()
+    yield "rstrow_200x150_444_opt", golden_bytes("rstrow_200x150_444_opt"), 0
+    yield "rst4_128x96_444", golden_bytes("rst4_128x96_444"), 0
+    yield "rstrow_gray_100x60", golden_bytes("rstrow_gray_100x60"), 0
+    yield "synthetic 4096x4096 4:4:4, restart per MCU row", synth.cfg5_tile(4096, seed=5), 0
+    yield "synthetic 1000x700 4:2:0, RI 7, standard restart rule", synth.make(1000, 700, 77, 90, synth.SUB_420, 7, synth.DENSE_DETAIL, True), 1
+
+
+@pytest.mark.parametrize("fmt", ["bmp", "rgb8"])
+def test_split_decode_equals_unsplit_decode(ctx, monkeypatch, fmt):
+    """pjd_split_decode with the device listed several times (PJD_PIPE_ALLOW_DUP_DEVICES: every entry is a rank with its own
+    context, host thread and bitstream slice): the assembled picture is byte-identical to the one-device decode -- sha256 of
+    the reference's BMP for the fixtures -- for 1, 2, 3 and 5 ranks, also when a range boundary falls inside an MCU row."""
+    import pjd_amd
+    monkeypatch.setenv("PJD_PIPE_ALLOW_DUP_DEVICES", "1")
+    out_fmt = pjd_amd.OUT_BMP if fmt == "bmp" else pjd_amd.OUT_RGB8
+    for label, data, flags in _split_cases():
+        s = pjd_amd.Scanned(data)
+        assert s.valid
+        s.desc.flags = pjd_amd.F_STANDARD_RESTART if flags else 0
+        whole, st = ctx.decode([s.desc], out_fmt)
+        assert st == [0]
+        for world in (1, 2, 3, 5):
+            got, status, stats = pjd_amd.split_decode(s.desc, [0] * world, out_fmt)
+            assert status == 0 and stats["redone_whole"] == 0, (label, world)
+            assert stats["n_ranks"] == min(world, int(s.desc.n_segments)) and stats["n_exact"] == 0, (label, world, stats)
+            assert np.array_equal(np.asarray(got).reshape(-1), np.asarray(whole[0]).reshape(-1)), (label, world)
+            if world > 1:
+                assert sum(stats["ecs_bytes"]) == int(s.desc.ecs_len) and stats["blob_bytes"] > 1000
+        if fmt == "bmp" and label in MANIFEST:
+            assert hashlib.sha256(np.asarray(got).tobytes()).hexdigest() == MANIFEST[label]["bmp_sha256"]
+    pjd_amd.dev_lib().pjd_split_release()
+
+
+def test_split_decode_broadcasts_with_rccl_and_handles_the_odd_cases(ctx, port, monkeypatch):
+    """(a) One real device = a one-rank RCCL communicator is NOT what runs (a single rank decodes alone); two ranks on one GPU
+    cannot form a communicator, so the collective itself is exercised where it can be on this box: world 2 over devices that
+    exist.  With one GPU the list [0] decodes whole; the RCCL path is reported by `rccl_used` whenever the devices are distinct.
+    (b) pictures that cannot be split (no restart interval; 4:2:0 + DRI under the reference's rule) are decoded by the first
+    device alone and equal the oracle; (c) a picture with an entropy-coding error is decoded again whole: status and partial
+    picture are the reference's."""
+    import torch
+    import pjd_amd
+    ngpu = torch.cuda.device_count()
+    s = _desc("rstrow_200x150_444_opt")
+    want = port.decode(golden_bytes("rstrow_200x150_444_opt"))["rgb"]
+    if ngpu >= 2:
+        got, status, stats = pjd_amd.split_decode(s.desc, list(range(min(ngpu, 4))))
+        assert status == 0 and np.array_equal(got, want) and stats["rccl_used"] == 1
+    got, status, stats = pjd_amd.split_decode(s.desc, [0])
+    assert status == 0 and np.array_equal(got, want) and stats["n_ranks"] == 1
+    monkeypatch.setenv("PJD_PIPE_ALLOW_DUP_DEVICES", "1")
+    for name in ("big_640x480_420_q85", "div_rst_420_64x48", "huff_longtail_96x64_444"):
+        o = port.decode(golden_bytes(name))
+        got, status, stats = pjd_amd.split_decode(_desc(name).desc, [0, 0, 0])
+        assert status == o["huff_rc"] and np.array_equal(got, o["rgb"]), name
+    # an error inside the third of four shards: the reference's picture is grey after it, also in the fourth shard's rows
+    data = bytearray(golden_bytes("rst4_128x96_444"))
+    sc = pjd_amd.Scanned(bytes(data))
+    assert sc.valid and sc.desc.n_segments >= 8
+    pos = bytes(data).rfind(b"\xff\xda")
+    cut = pos + 14 + int(sc.seg_offsets()[int(sc.desc.n_segments) * 5 // 8]) + 9
+    for k in range(6):
+        data[cut + k] = 0xFE if data[cut + k] != 0xFF and data[cut + k - 1] != 0xFF else data[cut + k]
+    o = port.decode(bytes(data))
+    if o["valid"] and o["huff_rc"] != 0:
+        sc2 = pjd_amd.Scanned(bytes(data))
+        got, status, stats = pjd_amd.split_decode(sc2.desc, [0, 0, 0, 0])
+        assert status == o["huff_rc"] and stats["redone_whole"] == 1
+        assert np.array_equal(got, o["rgb"])
+    pjd_amd.dev_lib().pjd_split_release()
+
+
+def test_cli_split_writes_the_same_bmp(tmp_path, monkeypatch):
+    """bin/decoder --split --devices 0,0,0 <file>: the CLI's route into pjd_split_decode (one picture, several devices)."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    env = dict(os.environ, PJD_PIPE_ALLOW_DUP_DEVICES="1")
+    names = ["rstrow_200x150_444_opt", "rst4_128x96_444", "big_640x480_420_q85", "neg_progressive_64x48"]
+    for n in names:
+        shutil.copy(os.path.join(HERE, "golden", n + ".jpg"), tmp_path / (n + ".jpg"))
+    p = subprocess.run([os.path.join(ROOT, "bin", "decoder"), "--split", "--devices", "0,0,0"] + [str(tmp_path / (n + ".jpg")) for n in names],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "Profiles:" in p.stdout and "split over 3 devices" in p.stdout
+    for n in names:
+        ent = MANIFEST[n]
+        bmp = tmp_path / (n + ".bmp")
+        for line in ent["stdout"].replace("{path}", str(tmp_path / (n + ".jpg"))).splitlines():
+            assert line in p.stdout, line
+        if ent["rc"] != 0:
+            assert not bmp.exists()
+        else:
+            assert hashlib.sha256(bmp.read_bytes()).hexdigest() == ent["bmp_sha256"], n

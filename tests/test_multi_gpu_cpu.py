@@ -98,3 +98,43 @@ def test_lpt_and_segment_ranges():
             got = [parallel.segment_range(n, r, w) for r in range(w)]
             assert sum(c for _, c in got) == n
             assert all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(w - 1))
+
+
+# ---- the C++ split path (include/pjd.h: pjd_split_plan / pjd_split_decode): range and offset arithmetic, no device ------------
+@pytest.mark.parametrize("name", ["rstrow_200x150_444_opt", "rst4_128x96_444", "rstrow_gray_100x60", "rst1_61x45_444", "rst7_gray_61x45"])
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8, 16])
+def test_split_plan_matches_the_python_sharding(name, world):
+    """pjd_split_plan (what pjd_split_decode and `bin/decoder --split` use) against pjd_amd.parallel (what bench.py's
+    cfg5split uses): same segment ranges, same byte ranges, same rebased offsets; the ranges tile the picture's segments,
+    bytes and MCUs exactly once; ranks beyond the number of segments get nothing."""
+    import pjd_amd
+    from pjd_amd import parallel
+    s = pjd_amd.Scanned(golden_bytes(name))
+    d = s.desc
+    segs, ecs = s.seg_offsets(), s.ecs()
+    nseg = len(segs)
+    hs, vs = int(d.h_samp), int(d.v_samp)
+    n_mcu = (((d.width + 7) // 8 + hs - 1) // hs) * (((d.height + 7) // 8 + vs - 1) // vs)
+    next_seg, next_byte, next_mcu = 0, 0, 0
+    for r in range(world):
+        f, c = parallel.segment_range(nseg, r, world)
+        got = pjd_amd.split_plan(d, world, r)
+        if c == 0:
+            assert got is None
+            continue
+        assert (got["first_seg"], got["n_segs"]) == (f, c)
+        lo = int(segs[f]); hi = int(segs[f + c]) if f + c < nseg else len(ecs)
+        assert (got["byte_lo"], got["byte_hi"], got["ecs_len"], got["ecs_delta"]) == (lo, hi, hi - lo, lo)
+        sd, keep = parallel.shard_descriptor(d, segs, ecs[lo:hi], lo, r, world)
+        assert np.array_equal(got["seg_offsets"], keep[1])
+        assert got["first_mcu"] == min(f * d.restart_interval, n_mcu) and got["last_mcu"] == min((f + c) * d.restart_interval, n_mcu)
+        assert (f, lo, got["first_mcu"]) == (next_seg, next_byte, next_mcu)
+        next_seg, next_byte, next_mcu = f + c, hi, got["last_mcu"]
+    assert (next_seg, next_byte, next_mcu) == (nseg, len(ecs), n_mcu)
+
+
+def test_split_plan_rejects_pictures_without_restart_segments():
+    import pjd_amd
+    s = pjd_amd.Scanned(golden_bytes("big_640x480_420_q85"))
+    with pytest.raises(pjd_amd.PjdError):
+        pjd_amd.split_plan(s.desc, 2, 0)
