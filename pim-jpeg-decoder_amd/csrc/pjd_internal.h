@@ -27,6 +27,9 @@
 // (4 checkpoints, 16 staged entries) measured best with batches in flight (+1 % on the default input, +5 % on the lighter one
 // against 4 waves with 4 KB areas), equal within noise for one batch at a time.
 #define PJD_WAVE_LDS       (PJD_CHK_BYTES > PJD_STAGE_BYTES ? PJD_CHK_BYTES : PJD_STAGE_BYTES)
+// per wave: the phase table -- one 16-byte record per data unit of the MCU: what the NEXT unit decodes with (table offsets,
+// its own record's address, the DC-sum selectors of its component); a unit's completion is one LDS read instead of ~9 VALU
+#define PJD_PHASE_LDS      256      // 16 records (an MCU has at most 4 + 2 = 6 units; sampling 2x2 with three components)
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
 #define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one table set in LDS; larger -> exact kernel
@@ -79,10 +82,12 @@ enum {
     PJD_FLAG_TIMEOUT,        // a bounded wait on another wave expired, or that wave was poisoned
     PJD_FLAG_OVERFLOW,       // a lane needed more than PJD_LANE_CAP entries
     PJD_FLAG_VERIFY,         // the write pass did not reproduce the synchronised exit state / unit count
+    PJD_FLAG_RUN,            // a run/size symbol landed past slot 63 (reference jpeg_scanner.cpp:500); seen by the back end's parser,
+                             //   counted per IDCT workgroup
     PJD_FLAG_REASONS
 };
 #define PJD_STAT_FLAG0 4
-#define PJD_STAT_ENTRIES 11  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
+#define PJD_STAT_ENTRIES 12  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
 
 struct PjdDevImage {
     uint32_t width, height;
@@ -123,13 +128,17 @@ struct PjdDevHuffRaw {
 // files written with the Annex-K tables has a single set), and so can the waves of one Huffman workgroup.
 // Decode-ready form, built on the device by pjd_k_build_tables, one blob per set:
 //   [table 0 L1][table 1 L1]...[table n-1 L1][second-level regions, 64 u16 per long prefix]
-// L1 is indexed by the next PJD_LUT_BITS bits.  Entry (u16):
-//   bit 15 = 0 : bits 4..0 = bits consumed by the symbol (code length + size), bits 8..5 = run, bits 12..9 = size,
-//                bit 13 = EOB (AC tables only), bit 14 = error (no code starts with these bits: consume 16 as the
-//                reference's get_next_symbol does; DC size > 11; AC size > 10)
-//   bit 15 = 1 : codes with this prefix are longer than 10 bits; bits 14..0 = u16 index (relative to the blob)
-//                of the prefix's 64-entry second-level table, indexed by the following 6 bits; entries there
-//                have the first form with code lengths 11..16.
+// L1 is indexed by the next PJD_LUT_BITS bits.  Entry (u16), round-3 layout -- every field the per-symbol loops need comes out
+// with one AND or one bit-field extract, and the zigzag bookkeeping is ONE subtraction (see PJD_LUT_ADV):
+//   bits  4..0  bits consumed by the symbol (code length + value bits), 1..27; 0 marks a pointer entry (below)
+//   bits 10..5  "advance": run + 1 for an AC run/size symbol, 1 for a DC symbol; bit 10 is always 0
+//   bit  11     EOB (AC tables only).  Bits 11..5 read as ONE 7-bit number are the slots the symbol uses up -- 65 for an EOB,
+//               more than any unit has left -- so "63 - slot" minus that number going negative is "the unit is complete"
+//   bits 15..12 value bits (size) 0..11; 15 = invalid: no code starts with these bits (then 16 bits are consumed, as the
+//               reference's get_next_symbol does), a DC size > 11 or an AC size > 10 (the code alone is consumed)
+//   pointer entry (bits 4..0 == 0): codes with this 10-bit prefix are longer than 10 bits; bits 15..5 = u16 index (relative to the
+//               blob) / 64 of the prefix's 64-entry second-level table, indexed by the following 6 bits; entries there have the
+//               first form with code lengths 11..16.
 // Canonical codes keep all long codes in one contiguous range of prefixes [p0, p1), so the second level
 // costs 128 bytes per long prefix (Annex K tables: 5 prefixes for an AC table, 0..1 for a DC table).
 struct PjdDevTset {
@@ -141,11 +150,11 @@ struct PjdDevTset {
     uint16_t l2_p1[PJD_MAX_TABLES];
 };
 #define PJD_LUT_USED(e)  ((e) & 31u)
-#define PJD_LUT_RUN(e)   (((e) >> 5) & 15u)
-#define PJD_LUT_SIZE(e)  (((e) >> 9) & 15u)
-#define PJD_LUT_EOB      0x2000u
-#define PJD_LUT_ERR      0x4000u
-#define PJD_LUT_L2       0x8000u
+#define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1, + 64 for an EOB
+#define PJD_LUT_SIZE(e)  ((e) >> 12)              // of a 16-bit entry
+#define PJD_LUT_EOB      0x0800u
+#define PJD_LUT_BADSIZE  15u
+#define PJD_LUT_ENTRY(used, adv, eob, size)  ((used) | ((adv) << 5) | ((eob) ? PJD_LUT_EOB : 0u) | ((size) << 12))
 
 struct PjdDevSegment {                 // one restart segment
     uint32_t byte_start;               // relative to the image's ecs

@@ -47,22 +47,23 @@ static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
 static_assert(PJD_LUT_BITS == 10, "second level is indexed by the 6 bits after a 10-bit prefix");
 static_assert(PJD_HUFF_LANES == 64, "one wave per 64 lanes");
 
-#define LUT_BAD     (PJD_LUT_ERR | 16u)          // no code: consume 16 bits (as the reference's get_next_symbol)
+#define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSIZE)   // no code: consume 16 bits (as the reference's get_next_symbol)
 
 // ---------------------------------------------------------------------------------------------
 // One block per (table set, table slot): two-level decode table (layout: pjd_internal.h).
 __device__ __forceinline__ uint32_t lut_entry(uint32_t len, uint32_t sym, bool is_ac)
 {
-    uint32_t run = 0, size, flags = 0;
+    uint32_t run = 0, size;
+    bool eob = false, bad = false;
     if (is_ac) {
         run = sym >> 4; size = sym & 15u;
-        if (sym == 0) flags = PJD_LUT_EOB;
-        else if (size > 10) { flags = PJD_LUT_ERR; size = 0; }          // jpeg_scanner.cpp:506
+        if (sym == 0) eob = true;
+        else if (size > 10) bad = true;                                 // jpeg_scanner.cpp:506
     } else {
         size = sym;
-        if (sym > 11) { flags = PJD_LUT_ERR; size = 0; }                // jpeg_scanner.cpp:474
+        if (sym > 11) bad = true;                                       // jpeg_scanner.cpp:474
     }
-    return (len + size) | (run << 5) | (size << 9) | flags;
+    return PJD_LUT_ENTRY(len + (bad ? 0u : size), run + 1, eob, bad ? PJD_LUT_BADSIZE : size);
 }
 
 __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
     if (tid < 17) offs[tid] = r.offsets[tid];
     __syncthreads();
     for (uint32_t idx = tid; idx < (1u << PJD_LUT_BITS); idx += 256) {
-        uint32_t e = (idx >= p0 && idx < p1) ? (PJD_LUT_L2 | (l2_off + (idx - p0) * 64)) : LUT_BAD;
+        uint32_t e = (idx >= p0 && idx < p1) ? (((l2_off + (idx - p0) * 64) >> 6) << 5) : LUT_BAD;      // pointer entry: bits 4..0 == 0
         for (uint32_t len = 1; len <= PJD_LUT_BITS; len++) {     // shortest match wins, as the reference's scan
             const uint32_t c = idx >> (PJD_LUT_BITS - len);
             const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
@@ -174,23 +175,53 @@ struct BitWin {
     }
 };
 
-// Data-unit phase inside the MCU, kept as r = units of the MCU still to come after the current one (dus-1 .. 0):
-// the luma units come first, so the component is 0 while r >= nc (nc = chroma components), else nc - r.  The table
-// offsets (LDS byte offset of the DC table | AC table << 16) of the three components are wave-uniform.
+// LDS is addressed by ABSOLUTE byte address (the tables' offsets carry the base of the kernel's dynamic LDS): indexing a pointer
+// derived from the extern array makes the compiler add that base -- a link-time constant it cannot fold -- on every access.
+__device__ __forceinline__ uint32_t lds_abs(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(a); }
+typedef uint32_t pjd_v2u32 __attribute__((ext_vector_type(2)));
+typedef uint32_t pjd_v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_u32x2(uint32_t a)
+{
+    const pjd_v2u32 v = *reinterpret_cast<const __attribute__((address_space(3))) pjd_v2u32 *>(a);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 lds_u32x4(uint32_t a)
+{
+    const pjd_v4u32 v = *reinterpret_cast<const __attribute__((address_space(3))) pjd_v4u32 *>(a);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Data-unit phase inside the MCU.  Unit k of an MCU (luma units first) is kept as r = units of the MCU still to come after it
+// (dus-1 .. 0): the component is 0 while r >= nc (nc = chroma components), else nc - r.  What a unit decodes with -- the absolute
+// LDS byte addresses of its DC and AC tables (below 64 KB), packed DC | AC << 16 -- and which DC sum its difference goes to is looked up in the
+// wave's PHASE TABLE in LDS: record r (16 bytes) describes the unit that FOLLOWS unit r, so completing a unit is one read:
+//   .x  table offsets of the next unit        .y  LDS byte address of the next unit's own record
+//   .z  mask of (dv | dv << 16) for the packed sums {Y | Cb << 16}         .w  the same for {Cr}
 struct PhaseCtx {
-    uint32_t tY, tC1, tC2;     // wave-uniform
+    uint32_t tY, tC1, tC2;     // wave-uniform table addresses (DC | AC << 16) of the three components
     uint32_t nc, dus1;         // chroma components; data units per MCU - 1
-    // v_cndmask by hand: written as nested ?: the compiler builds a three-entry table in scratch memory and loads from it
-    static __device__ __forceinline__ uint32_t sel(bool c, uint32_t t, uint32_t f)
-    {
-        uint32_t d;
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(__builtin_amdgcn_ballot_w64(c)));
-        return d;
-    }
-    // the last unit of the MCU (r == 0) belongs to the last component (tC2 == tC1 when there is one chroma component)
-    __device__ __forceinline__ uint32_t tabs(uint32_t r) const { return sel(r >= nc, tY, sel(r == 0, tC2, tC1)); }
+    uint32_t xbase;            // LDS byte address of this wave's phase table
+    uint32_t lbase;            // LDS byte address of the table blob (second-level tables are indexed from it)
+    __device__ __forceinline__ uint32_t tabs(uint32_t r) const { return r >= nc ? tY : (r == 0 ? tC2 : tC1); }
     __device__ __forceinline__ uint32_t comp(uint32_t r) const { return r >= nc ? 0u : nc - r; }
     __device__ __forceinline__ uint32_t next(uint32_t r) const { return r == 0 ? dus1 : r - 1; }
+    // lanes 0..dus1 of the wave write the table (before the wave's first pass; the wave is converged)
+    __device__ __forceinline__ void build(uint32_t lane) const
+    {
+        if (lane <= dus1) {
+            const uint32_t rn = next(lane), cn = comp(rn);
+            uint4 rec;
+            rec.x = tabs(rn);
+            rec.y = xbase + rn * 16;
+            rec.z = cn == 0 ? 0x0000ffffu : (cn == 1 ? 0xffff0000u : 0u);
+            rec.w = cn == 2 ? 0x0000ffffu : 0u;
+            pjd_v4u32 v; v.x = rec.x; v.y = rec.y; v.z = rec.z; v.w = rec.w;
+            *reinterpret_cast<__attribute__((address_space(3))) pjd_v4u32 *>(xbase + lane * 16) = v;
+        }
+    }
+    // the record that describes unit r itself = the one stored at its predecessor in the cycle
+    __device__ __forceinline__ uint32_t self(uint32_t r) const { return xbase + (r == dus1 ? 0u : r + 1) * 16; }
 };
 
 struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided by lane)
@@ -207,21 +238,31 @@ __device__ __forceinline__ void chk_finish(const ChkCtx &K, uint32_t j, uint32_t
     for (uint32_t i = 1; i < j; i++) K.rem[i * 64] = ndu - K.rem[i * 64];
 }
 
-__device__ __forceinline__ uint32_t lut_lookup(const uint8_t *lds, uint32_t tab, uint32_t pk)
+__device__ __forceinline__ uint32_t lut_lookup(uint32_t lbase, uint32_t tab, uint32_t pk)
 {
-    uint32_t e = *reinterpret_cast<const uint16_t *>(lds + tab + 2 * (pk >> (32 - PJD_LUT_BITS)));
-    // code longer than 10 bits: one more read, in the 64-entry table of this 10-bit prefix
-    if (__builtin_expect((e & PJD_LUT_L2) != 0, 0))
-        e = *reinterpret_cast<const uint16_t *>(lds + 2 * ((e & 0x7fffu) + ((pk >> 16) & 63u)));
+    uint32_t e = lds_u16(tab + 2 * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS));
+    // code longer than 10 bits (a pointer entry consumes no bits): one more read, in the 64-entry table of this 10-bit prefix
+    if (__builtin_expect(PJD_LUT_USED(e) == 0, 0))
+        e = lds_u16(lbase + 2 * (((e >> 5) << 6) + ((pk >> 16) & 63u)));
     return e;
+}
+
+// ndu += vcc ? 1 : 0 in one instruction (the compiler emits a select and an add)
+__device__ __forceinline__ uint32_t add_flag(uint32_t v, bool f)
+{
+    uint32_t d;
+    asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(d) : "v"(v), "s"(__builtin_amdgcn_ballot_w64(f)) : "vcc");
+    return d;
 }
 
 // STATE-ONLY pass: decodes symbols that START before end_bit.  State (p, c, z): bit position relative to the
 // lane's first byte, data-unit phase within the MCU, zigzag slot (0 = DC expected).  BRIDGE: stop as soon as
 // the state equals the checkpoint recorded by an earlier pass (then ndu already includes the units still to
 // come); otherwise (re)write the checkpoints passed.  Returns the number of checkpoints passed + 1 in `jout`.
+// Inside the loop the slot is kept as zb = 63 - z (63: DC expected) and the phase as the LDS address of the unit's
+// phase record: one symbol is a table lookup, "zb -= advance", and three selects when the unit is complete.
 template <bool BRIDGE>
-__device__ __forceinline__ int sync_span(const uint8_t *lds, const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
+__device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
                                          uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                          uint32_t &ndu, const ChkCtx &K, uint32_t &jout)
 {
@@ -230,32 +271,35 @@ __device__ __forceinline__ int sync_span(const uint8_t *lds, const PhaseCtx &P, 
     if (p >= end_bit) return SPAN_END;
     BitWin w;
     w.init(wave_words, lane, p);
-    uint32_t r = P.dus1 - c;
-    uint32_t x = P.tabs(r);
+    uint32_t ra, x;
+    {
+        const uint2 cur = lds_u32x2(P.self(P.dus1 - c));
+        x = cur.x; ra = cur.y;
+    }
+    int zb = 63 - (int)z;
     uint32_t next_chk = K.chk_bits;
     uint32_t lim = next_chk < end_bit ? next_chk : end_bit;     // one compare per symbol covers "subsequence end" and "next checkpoint"
     int res = SPAN_END;
     // on entry p < lim: p <= 26 bits (a symbol that started before the lane's first byte) and p < end_bit
     for (;;) {
         const uint32_t pk = w.peek();
-        const uint32_t tab = (z == 0) ? (x & 0xffffu) : (x >> 16);
-        const uint32_t e = lut_lookup(lds, tab, pk);
+        const uint2 nx = lds_u32x2(ra);                                     // what follows this unit: issued beside the table lookup
+        const uint32_t tab = (zb == 63) ? (x & 0xffffu) : (x >> 16);
+        const uint32_t e = lut_lookup(P.lbase, tab, pk);
         const uint32_t used = PJD_LUT_USED(e);
         w.drop(used);
         p += used;
-        // state update without branches (reference src/jpeg_scanner.cpp:469-518): a DC symbol has run 0 and
-        // never carries the EOB bit, so z -> z + run + 1 covers it; a run past slot 63 ends the unit here (the
-        // write pass reports it)
-        const uint32_t z1 = z + PJD_LUT_RUN(e) + 1;
-        const bool done = (((e >> 7) & 64u) | z1) > 63u;                    // EOB, or the unit's last slot was filled
-        const uint32_t rn = P.next(r);
-        z = done ? 0u : z1;
-        r = done ? rn : r;
-        x = done ? P.tabs(rn) : x;
-        ndu += done ? 1u : 0u;
+        // state update (reference src/jpeg_scanner.cpp:469-518): a DC symbol advances one slot and never carries the EOB bit; a
+        // run past slot 63 ends the unit here (the back end's parser reports it)
+        zb -= (int)PJD_LUT_ADV(e);
+        const bool done = zb < 0;                                           // EOB, or the unit's last slot was filled
+        zb = done ? 63 : zb;
+        ra = done ? nx.y : ra;
+        x = done ? nx.x : x;
+        ndu = add_flag(ndu, done);
         if (p >= lim) {
             if (p >= end_bit) break;
-            const uint32_t st = (p << 12) | (r << 8) | z;                  // p < 2^14, r < 16, z < 64
+            const uint32_t st = (p << 14) | ((ra - P.xbase) << 6) | (uint32_t)zb;      // p < 2^14, record offset < 256, zb < 64
             if (BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
             K.state[j * 64] = st;
             K.rem[j * 64] = ndu;                                            // turned into "still to come" after the pass
@@ -264,7 +308,8 @@ __device__ __forceinline__ int sync_span(const uint8_t *lds, const PhaseCtx &P, 
             lim = next_chk < end_bit ? next_chk : end_bit;
         }
     }
-    c = P.dus1 - r;
+    c = P.dus1 - ((ra - P.xbase) >> 4);
+    z = 63u - (uint32_t)zb;
     jout = j;
     return res;
 }
@@ -277,7 +322,7 @@ struct OutCtx {
     uint32_t *stage;       // LDS: [16 rows][64 lanes] dwords at this lane's column: two entries per dword
     uint32_t cap;          // entries the region holds
     uint32_t n;            // entries emitted
-    uint32_t dcY, dcC;     // DC differences summed so far: Y | Cb (low) Cr (high), each mod 2^16
+    uint32_t dcA, dcB;     // DC differences summed so far, each mod 2^16: Y (low) Cb (high) | Cr (low)
     uint32_t left;         // data units to complete before the next unit that starts an IDCT workgroup's range
     uint32_t ru;           // data units per IDCT workgroup
     PjdDevMark *marks;     // of this image
@@ -299,50 +344,60 @@ __device__ __forceinline__ void stage_flush(const OutCtx &O, uint32_t first_entr
     }
 }
 
-// One symbol of the write pass.  Returns the 16-bit entry; updates the state.
-__device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const PhaseCtx &P, BitWin &w, uint32_t &p, uint32_t &z,
-                                               uint32_t &r, uint32_t &x, uint32_t &err, uint32_t &ov, uint32_t &D, OutCtx &O)
+struct WState {            // decoder state of the write pass, in registers
+    uint32_t p;
+    int zb;                // 63 - zigzag slot
+    uint32_t ra, x;        // phase record address, table offsets of the current unit
+    uint32_t mA, mB;       // DC-sum selectors of the current unit's component
+    uint32_t emax;         // max over the table entries seen: >= 0xf000 <=> an invalid symbol (size field 15)
+};
+
+typedef unsigned short pjd_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
 {
-    const bool is_dc = (z == 0);
+    return __builtin_bit_cast(uint32_t, (pjd_u16x2)(__builtin_bit_cast(pjd_u16x2, a) + __builtin_bit_cast(pjd_u16x2, b)));
+}
+
+// One symbol of the write pass.  Returns the 16-bit entry; updates the state.
+__device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState &S, uint32_t &D, OutCtx &O)
+{
+    const bool is_dc = (S.zb == 63);
     if (__builtin_expect(is_dc && O.left == 0, 0)) {                        // this unit opens an IDCT workgroup's range
         PjdDevMark m;
         m.lane = O.lane_q; m.ent_off = O.n;
-        m.acc[0] = (uint16_t)O.dcY; m.acc[1] = (uint16_t)O.dcC; m.acc[2] = (uint16_t)(O.dcC >> 16); m.pad_ = 0;
+        m.acc[0] = (uint16_t)O.dcA; m.acc[1] = (uint16_t)(O.dcA >> 16); m.acc[2] = (uint16_t)O.dcB; m.pad_ = 0;
         O.marks[O.mark_next++] = m;
         O.left = O.ru;
     }
     const uint32_t pk = w.peek();
-    const uint32_t tab = is_dc ? (x & 0xffffu) : (x >> 16);
-    const uint32_t e = lut_lookup(lds, tab, pk);
-    const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e), run = PJD_LUT_RUN(e);
-    // value: `size` bits after the code, sign-extended the JPEG way (jpeg_scanner.cpp:478-484,510-516)
+    const uint4 nx = lds_u32x4(S.ra);                                       // the unit after this one
+    const uint32_t tab = is_dc ? (S.x & 0xffffu) : (S.x >> 16);
+    const uint32_t e = lut_lookup(lbase, tab, pk);
+    const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e), adv = PJD_LUT_ADV(e);
+    // value: `size` bits after the code, sign-extended the JPEG way (jpeg_scanner.cpp:478-484,510-516); an invalid entry
+    // (size field 15) yields garbage here and sends the picture to the exact kernel through S.emax
     const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size);
     const uint32_t m1 = 1u << size;
     const int val = (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
     w.drop(used);
-    p += used;
-    err |= e;
-    const uint32_t z1 = z + run + 1;
-    ov |= z1 + 63;                                                          // bit 7: run past slot 63 (jpeg_scanner.cpp:500)
-    const bool done = (((e >> 7) & 64u) | z1) > 63u;
-    // entry (layout: pjd_internal.h); the field above the value is the run, or bit 11 of a DC difference
-    const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : run;
+    S.p += used;
+    S.emax = S.emax > e ? S.emax : e;
+    S.zb -= (int)adv;
+    const bool done = S.zb < 0;
+    // entry (layout: pjd_internal.h); the field above the value is the run (advance - 1; an EOB's 64 drops out), or bit 11 of a DC difference
+    const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : ((adv - 1u) & 15u);
     const uint32_t ent = ((uint32_t)val & 0x7ffu) | (top << 12) | (done ? PJD_ENT_LAST : 0u);
     // DC sums of this lane, per component (the predictors come from a scan over lanes)
-    const uint32_t comp = P.comp(r);
-    const uint32_t dv = is_dc ? (uint32_t)val & 0xffffu : 0u;
-    O.dcY += comp == 0 ? dv : 0u;
-    {
-        const uint32_t addc = comp == 1 ? dv : (comp == 2 ? dv << 16 : 0u);
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        const u16x2 a = __builtin_bit_cast(u16x2, O.dcC), b = __builtin_bit_cast(u16x2, addc);
-        O.dcC = __builtin_bit_cast(uint32_t, (u16x2)(a + b));
-    }
-    const uint32_t rn = P.next(r);
-    z = done ? 0u : z1;
-    r = done ? rn : r;
-    x = done ? P.tabs(rn) : x;
-    D += done ? 1u : 0u;
+    const uint32_t dv = is_dc ? ((uint32_t)val & 0xffffu) : 0u;
+    const uint32_t dvv = dv | (dv << 16);
+    O.dcA = pk_add16(O.dcA, dvv & S.mA);
+    O.dcB = pk_add16(O.dcB, dvv & S.mB);
+    S.zb = done ? 63 : S.zb;
+    S.ra = done ? nx.y : S.ra;
+    S.x = done ? nx.x : S.x;
+    S.mA = done ? nx.z : S.mA;
+    S.mB = done ? nx.w : S.mB;
+    D = add_flag(D, done);
     O.left -= done ? 1u : 0u;
     return ent;
 }
@@ -350,21 +405,24 @@ __device__ __forceinline__ uint32_t write_step(const uint8_t *lds, const PhaseCt
 // Decodes from (p, c, z) until end_bit or until the segment's last data unit is complete (D == D_end).
 // Every active lane emits exactly one entry per step, so the entry count is the same in all of them and the
 // staging buffer is flushed by the whole wave at once.
-__device__ __forceinline__ void write_span(const uint8_t *lds, const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
+__device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
                                            uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                            uint32_t &err, uint32_t &D, uint32_t D_end, OutCtx &O)
 {
     BitWin w;
     w.init(wave_words, lane, p);
-    uint32_t r = P.dus1 - c;
-    uint32_t x = P.tabs(r);
-    uint32_t ov = 0;
+    WState S;
+    S.p = p; S.zb = 63 - (int)z; S.emax = 0;
+    {
+        const uint4 cur = lds_u32x4(P.self(P.dus1 - c));
+        S.x = cur.x; S.ra = cur.y; S.mA = cur.z; S.mB = cur.w;
+    }
     for (;;) {
-        if (p >= end_bit || D >= D_end) break;
-        const uint32_t e0 = write_step(lds, P, w, p, z, r, x, err, ov, D, O);
+        if (S.p >= end_bit || D >= D_end) break;
+        const uint32_t e0 = write_step(P.lbase, w, S, D, O);
         O.n++;
-        if (p >= end_bit || D >= D_end) { O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0; break; }
-        const uint32_t e1 = write_step(lds, P, w, p, z, r, x, err, ov, D, O);
+        if (S.p >= end_bit || D >= D_end) { O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0; break; }
+        const uint32_t e1 = write_step(P.lbase, w, S, D, O);
         O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0 | (e1 << 16);
         O.n++;
         if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {
@@ -373,8 +431,10 @@ __device__ __forceinline__ void write_span(const uint8_t *lds, const PhaseCtx &P
         }
     }
     if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
-    err |= (ov & 0x80u) << 7;
-    c = P.dus1 - r;
+    err = S.emax >= (PJD_LUT_BADSIZE << 12) ? 1u : 0u;
+    p = S.p;
+    c = P.dus1 - ((S.ra - P.xbase) >> 4);
+    z = 63u - (uint32_t)S.zb;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -390,7 +450,7 @@ struct LaneGeom {
     pjd_gptr words;                // wave-uniform: row 0 of the wave's transposed word rows
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][wave areas PJD_HUFF_WAVES x PJD_WAVE_LDS][ticket]
+extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][wave areas PJD_HUFF_WAVES x PJD_WAVE_LDS][phase tables PJD_HUFF_WAVES x PJD_PHASE_LDS][ticket]
 
 // Lanes have different origins, so states are exchanged as bit positions relative to the image's ecs.
 struct WaveState { uint32_t p_img, cz, cnt; };
@@ -413,7 +473,7 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
         changed = 0;
         if (act) {
             uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, j;
-            const int res = sync_span<true>(pjd_huff_lds, P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
+            const int res = sync_span<true>(P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
             chk_finish(K, j, ndu);               // also after a merge: ndu then includes the units still to come
             S.cnt = ndu;
             if (res != SPAN_MERGED) {
@@ -514,7 +574,8 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     const uint32_t t = threadIdx.x, l = t & 63, wi = t >> 6;
     uint8_t *lds = pjd_huff_lds;
     uint8_t *areas = lds + B.max_lut_bytes;
-    uint32_t *tick = reinterpret_cast<uint32_t *>(areas + PJD_HUFF_WAVES * PJD_WAVE_LDS);
+    uint8_t *phase_tabs = areas + PJD_HUFF_WAVES * PJD_WAVE_LDS;
+    uint32_t *tick = reinterpret_cast<uint32_t *>(phase_tabs + PJD_HUFF_WAVES * PJD_PHASE_LDS);
     if (t == 0) *tick = atomicAdd(B.ticket, 1u);
     __syncthreads();
     const uint32_t gidx = rfl(*tick);
@@ -544,12 +605,16 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     {
         const uint32_t nl = rfl(im.n_luma), dus = rfl(im.dus_per_mcu), nc = dus - nl;
         const uint32_t c1 = nc >= 1 ? 1u : 0u, c2 = nc >= 2 ? 2u : c1;
-        P.tY  = rfl((uint32_t)im.tbl_slot[0][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[0][1] * PJD_L1_BYTES) << 16);
-        P.tC1 = rfl((uint32_t)im.tbl_slot[c1][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[c1][1] * PJD_L1_BYTES) << 16);
-        P.tC2 = rfl((uint32_t)im.tbl_slot[c2][0] * PJD_L1_BYTES | ((uint32_t)im.tbl_slot[c2][1] * PJD_L1_BYTES) << 16);
+        const uint32_t lb = lds_abs(lds);                   // the whole layout stays below 64 KB: addresses fit the 16-bit halves
+        P.lbase = lb;
+        P.tY  = rfl((lb + (uint32_t)im.tbl_slot[0][0] * PJD_L1_BYTES) | (lb + (uint32_t)im.tbl_slot[0][1] * PJD_L1_BYTES) << 16);
+        P.tC1 = rfl((lb + (uint32_t)im.tbl_slot[c1][0] * PJD_L1_BYTES) | (lb + (uint32_t)im.tbl_slot[c1][1] * PJD_L1_BYTES) << 16);
+        P.tC2 = rfl((lb + (uint32_t)im.tbl_slot[c2][0] * PJD_L1_BYTES) | (lb + (uint32_t)im.tbl_slot[c2][1] * PJD_L1_BYTES) << 16);
         P.nc = nc; P.dus1 = dus - 1;
+        P.xbase = lds_abs(phase_tabs) + wi * PJD_PHASE_LDS;
     }
     const uint32_t dus = P.dus1 + 1;
+    P.build(l);                                                // this wave's phase table (read by this wave only)
     __syncthreads();                                           // the last barrier: from here on waves run on their own
     if (!wave_on) return;
 
@@ -592,7 +657,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     {
         uint32_t p = 0, c = 0, z = 0, ndu = 0, j = 1;
         if (g.valid) {
-            sync_span<false>(lds, P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
+            sync_span<false>(P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
             chk_finish(K, j, ndu);
         }
         S.p_img = p + g.base_bit; S.cz = (c << 8) | z; S.cnt = ndu;
@@ -704,7 +769,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
             O.region = B.ent + (size_t)g.q * B.lane_cap;
             O.stage = area + l;
             O.cap = B.lane_cap;
-            O.n = 0; O.dcY = 0; O.dcC = 0; O.overflow = 0;
+            O.n = 0; O.dcA = 0; O.dcB = 0; O.overflow = 0;
             O.ru = im.idct_mcus * dus;
             O.marks = B.marks + im.iwg_base;
             O.lane_q = g.q;
@@ -716,10 +781,10 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 O.left = first_du + k * O.ru - D_in;
             }
             uint32_t err = 0;
-            write_span(lds, P, g.words, l, p, c, z, g.end_bit, err, D, D_end, O);
+            write_span(P, g.words, l, p, c, z, g.end_bit, err, D, D_end, O);
             li.n_ent = O.n;
-            li.dc_sum[0] = (uint16_t)O.dcY; li.dc_sum[1] = (uint16_t)O.dcC; li.dc_sum[2] = (uint16_t)(O.dcC >> 16);
-            if (err & PJD_LUT_ERR) flag |= 1u << PJD_FLAG_SYMBOL;
+            li.dc_sum[0] = (uint16_t)O.dcA; li.dc_sum[1] = (uint16_t)(O.dcA >> 16); li.dc_sum[2] = (uint16_t)O.dcB;
+            if (err) flag |= 1u << PJD_FLAG_SYMBOL;
             if (O.overflow) flag |= 1u << PJD_FLAG_OVERFLOW;
             if (D == D_end) {
                 if (p > g.seg_end_bit) flag |= 1u << PJD_FLAG_SEGMENT;
@@ -760,7 +825,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
 static size_t huff_lds_bytes(const PjdDevBatch &b)
 {
     static const size_t extra = [] { const char *e = std::getenv("PJD_EXTRA_LDS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();   // occupancy experiments
-    return (size_t)b.max_lut_bytes + PJD_HUFF_WAVES * PJD_WAVE_LDS + 16 + extra;
+    return (size_t)b.max_lut_bytes + PJD_HUFF_WAVES * (PJD_WAVE_LDS + PJD_PHASE_LDS) + 16 + extra;
 }
 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)

@@ -871,7 +871,8 @@ def test_split_decode_broadcasts_with_rccl_and_handles_the_odd_cases(ctx, port, 
     monkeypatch.setenv("PJD_PIPE_ALLOW_DUP_DEVICES", "1")
     for name in ("big_640x480_420_q85", "div_rst_420_64x48", "huff_longtail_96x64_444"):
         o = port.decode(golden_bytes(name))
-        got, status, stats = pjd_amd.split_decode(_desc(name).desc, [0, 0, 0])
+        sc = _desc(name)                    # keep the Scanned alive: its descriptor points into it
+        got, status, stats = pjd_amd.split_decode(sc.desc, [0, 0, 0])
         assert status == o["huff_rc"] and np.array_equal(got, o["rgb"]), name
     # an error inside the third of four shards: the reference's picture is grey after it, also in the fourth shard's rows
     data = bytearray(golden_bytes("rst4_128x96_444"))
