@@ -262,6 +262,9 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        if os.environ.get("PJD_DEBUG_STATS") and rank == 0:
+            print("[bench] wave timeline of the last decode issued with batches in flight:", file=sys.stderr, flush=True)
+            batches[-1].info()            # the library prints the timeline of this batch's last decode (stderr)
         r = {"jpegs": jpegs, "label": label, "dt": dt, "steps": steps, "split": split, "host_ms": {"generate": round(t_gen * 1e3, 1),
              "scan": round(t_scan * 1e3, 1), "upload": round(t_up * 1e3, 1)}}
         if split:

@@ -150,8 +150,7 @@ typedef struct pjd_batch_info {
     uint64_t flag_waves[8];            /* waves that sent their image to the exact kernel in the last decode, by reason:
                                           0 invalid symbol, 1 irregular segment end / phase, 2 re-sync did not converge,
                                           3 wave boundary did not stitch, 4 wait timed out, 5 lane output overflow,
-                                          6 write pass did not reproduce the synchronised state; 7 (counted per IDCT workgroup,
-                                          by the back end's parser) a run/size symbol landed past zigzag slot 63             */
+                                          6 write pass did not reproduce the synchronised state                     */
 } pjd_batch_info;
 
 /* ---- context --------------------------------------------------------------- */

@@ -11,6 +11,7 @@
 //   download one D2H copy per picture
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -680,6 +681,12 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
                 if (end > worst_end) { worst_end = end; worst = k; }
             }
             const double n = (double)nw;
+            {   // shader clock held during the kernel: cycles per 10 ns of every wave (bits 8.. of word 7), median
+                std::vector<uint32_t> cl;
+                for (size_t k = 0; k < nw; k++) { cl.push_back(d[k * 32 + 7] >> 8); d[k * 32 + 7] &= 0xffu; }
+                std::sort(cl.begin(), cl.end());
+                std::fprintf(stderr, "[pjd waves] shader clock while the waves ran: median %.2f GHz (min %.2f, max %.2f)\n", cl[nw / 2] / 160.0, cl.front() / 160.0, cl.back() / 160.0);
+            }
             std::fprintf(stderr, "[pjd waves] n %zu | mean(us): start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write+verify %.1f | max(us): %.1f %.1f %.1f %.1f %.1f %.1f\n",
                          nw, sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, sum[4] / n / 100, sum[5] / n / 100,
                          mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0, mx[4] / 100.0, mx[5] / 100.0);

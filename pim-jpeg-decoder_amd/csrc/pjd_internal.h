@@ -30,6 +30,12 @@
 // per wave: the phase table -- one 16-byte record per data unit of the MCU: what the NEXT unit decodes with (table offsets,
 // its own record's address, the DC-sum selectors of its component); a unit's completion is one LDS read instead of ~9 VALU
 #define PJD_PHASE_LDS      256      // 16 records (an MCU has at most 4 + 2 = 6 units; sampling 2x2 with three components)
+#ifndef PJD_TAIL_PRIO
+#define PJD_TAIL_PRIO      1        // waves in their second and later re-sync rounds raise their issue priority (s_setprio), see wave_rounds
+#endif
+#ifndef PJD_IDCT_PRIO
+#define PJD_IDCT_PRIO      0        // issue priority of the back end's waves (0..3)
+#endif
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
 #define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one table set in LDS; larger -> exact kernel
@@ -82,12 +88,10 @@ enum {
     PJD_FLAG_TIMEOUT,        // a bounded wait on another wave expired, or that wave was poisoned
     PJD_FLAG_OVERFLOW,       // a lane needed more than PJD_LANE_CAP entries
     PJD_FLAG_VERIFY,         // the write pass did not reproduce the synchronised exit state / unit count
-    PJD_FLAG_RUN,            // a run/size symbol landed past slot 63 (reference jpeg_scanner.cpp:500); seen by the back end's parser,
-                             //   counted per IDCT workgroup
     PJD_FLAG_REASONS
 };
 #define PJD_STAT_FLAG0 4
-#define PJD_STAT_ENTRIES 12  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
+#define PJD_STAT_ENTRIES 11  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
 
 struct PjdDevImage {
     uint32_t width, height;
@@ -131,9 +135,11 @@ struct PjdDevHuffRaw {
 // L1 is indexed by the next PJD_LUT_BITS bits.  Entry (u16), round-3 layout -- every field the per-symbol loops need comes out
 // with one AND or one bit-field extract, and the zigzag bookkeeping is ONE subtraction (see PJD_LUT_ADV):
 //   bits  4..0  bits consumed by the symbol (code length + value bits), 1..27; 0 marks a pointer entry (below)
-//   bits 10..5  "advance": run + 1 for an AC run/size symbol, 1 for a DC symbol; bit 10 is always 0
-//   bit  11     EOB (AC tables only).  Bits 11..5 read as ONE 7-bit number are the slots the symbol uses up -- 65 for an EOB,
-//               more than any unit has left -- so "63 - slot" minus that number going negative is "the unit is complete"
+//   bits 10..5  "advance": run + 1 for an AC run/size symbol, 1 for a DC symbol, 33 for an EOB
+//   bit  11     EOB (AC tables only).  Bits 11..5 read as ONE 7-bit number are the slots the symbol uses up -- 97 for an EOB,
+//               more than any unit has left -- so "63 - slot" minus that number going negative is "the unit is complete";
+//               a run/size symbol that lands past slot 63 (an error in the reference, jpeg_scanner.cpp:500) leaves -16..-2 there,
+//               an EOB -97..-35, a unit that ends exactly on slot 63 leaves -1: the write pass tells them apart with one minimum
 //   bits 15..12 value bits (size) 0..11; 15 = invalid: no code starts with these bits (then 16 bits are consumed, as the
 //               reference's get_next_symbol does), a DC size > 11 or an AC size > 10 (the code alone is consumed)
 //   pointer entry (bits 4..0 == 0): codes with this 10-bit prefix are longer than 10 bits; bits 15..5 = u16 index (relative to the
@@ -150,7 +156,7 @@ struct PjdDevTset {
     uint16_t l2_p1[PJD_MAX_TABLES];
 };
 #define PJD_LUT_USED(e)  ((e) & 31u)
-#define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1, + 64 for an EOB
+#define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 97 for an EOB
 #define PJD_LUT_SIZE(e)  ((e) >> 12)              // of a 16-bit entry
 #define PJD_LUT_EOB      0x0800u
 #define PJD_LUT_BADSIZE  15u

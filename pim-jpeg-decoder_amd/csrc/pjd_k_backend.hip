@@ -591,6 +591,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
     __shared__ uint32_t wagg[2][4][2];        // per chunk parity, per wave: (units completed << 16 | sum of run+1), max unit-start mark
 
+#if PJD_IDCT_PRIO
+    __builtin_amdgcn_s_setprio(PJD_IDCT_PRIO);
+#endif
     const PjdDevIdctWg wg = B.iwgs[blockIdx.x];
     const PjdDevImage &im = B.images[wg.image];
     if ((im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT)) return;   // the dense path redoes it
@@ -697,7 +700,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         }
         // scatter: de-zigzag + dequantise (reference src/jpeg_scanner.cpp:517, src/decoder_dpu.c:169-172)
         uint32_t u = run_units + (exc >> 16), a_pos = exc & 0xffffu;
-        bool past63 = false;                                    // a run/size symbol that lands past slot 63 (reference :500: an error)
 #pragma unroll
         for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
             if (i0 + k < cnt && u < n_du) {
@@ -707,7 +709,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                     const uint32_t m = mk[k] > mexc ? mk[k] : mexc;
                     const uint32_t slot = a_pos - m + (e[k] >> 12);
                     const bool term = (e[k] & 0xf7ffu) == 0;                     // EOB: completes the unit, stores nothing
-                    past63 = past63 || (!term && slot >= 64);
                     if (!term && slot < 64) {
                         const uint32_t comp = comp_of[u];
                         if (slot == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
@@ -717,12 +718,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             }
             a_pos += adv[k];
             u += last[k];
-        }
-        if (__builtin_expect(__any(past63), 0)) {               // the entropy decoder does not check this itself: the exact kernel takes the picture
-            if (lane == 0) {
-                atomicOr(reinterpret_cast<unsigned int *>(B.status + wg.image), PJD_STW_NEEDS_EXACT);
-                atomicAdd(B.stats + PJD_STAT_FLAG0 + PJD_FLAG_RUN, 1ull);
-            }
         }
         // carry into the next chunk: units done; A - M at the chunk end (all threads compute the same)
         {

@@ -63,7 +63,7 @@ __device__ __forceinline__ uint32_t lut_entry(uint32_t len, uint32_t sym, bool i
         size = sym;
         if (sym > 11) bad = true;                                       // jpeg_scanner.cpp:474
     }
-    return PJD_LUT_ENTRY(len + (bad ? 0u : size), run + 1, eob, bad ? PJD_LUT_BADSIZE : size);
+    return PJD_LUT_ENTRY(len + (bad ? 0u : size), eob ? 33u : run + 1, eob, bad ? PJD_LUT_BADSIZE : size);   // EOB: 33 + 64 = 97 slots (pjd_internal.h)
 }
 
 __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
@@ -290,7 +290,7 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
         w.drop(used);
         p += used;
         // state update (reference src/jpeg_scanner.cpp:469-518): a DC symbol advances one slot and never carries the EOB bit; a
-        // run past slot 63 ends the unit here (the back end's parser reports it)
+        // run past slot 63 ends the unit here (the write pass reports it)
         zb -= (int)PJD_LUT_ADV(e);
         const bool done = zb < 0;                                           // EOB, or the unit's last slot was filled
         zb = done ? 63 : zb;
@@ -350,6 +350,7 @@ struct WState {            // decoder state of the write pass, in registers
     uint32_t ra, x;        // phase record address, table offsets of the current unit
     uint32_t mA, mB;       // DC-sum selectors of the current unit's component
     uint32_t emax;         // max over the table entries seen: >= 0xf000 <=> an invalid symbol (size field 15)
+    uint32_t umin;         // min over the symbols of (63 - slot after the symbol) + 16, unsigned: <= 14 <=> a run past slot 63
 };
 
 typedef unsigned short pjd_u16x2 __attribute__((ext_vector_type(2)));
@@ -384,6 +385,7 @@ __device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState
     S.emax = S.emax > e ? S.emax : e;
     S.zb -= (int)adv;
     const bool done = S.zb < 0;
+    { const uint32_t u = (uint32_t)(S.zb + 16); S.umin = S.umin < u ? S.umin : u; }      // run past slot 63 (jpeg_scanner.cpp:500): -16..-2 here
     // entry (layout: pjd_internal.h); the field above the value is the run (advance - 1; an EOB's 64 drops out), or bit 11 of a DC difference
     const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : ((adv - 1u) & 15u);
     const uint32_t ent = ((uint32_t)val & 0x7ffu) | (top << 12) | (done ? PJD_ENT_LAST : 0u);
@@ -412,7 +414,7 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
     BitWin w;
     w.init(wave_words, lane, p);
     WState S;
-    S.p = p; S.zb = 63 - (int)z; S.emax = 0;
+    S.p = p; S.zb = 63 - (int)z; S.emax = 0; S.umin = 0xffffffffu;
     {
         const uint4 cur = lds_u32x4(P.self(P.dus1 - c));
         S.x = cur.x; S.ra = cur.y; S.mA = cur.z; S.mB = cur.w;
@@ -431,7 +433,7 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
         }
     }
     if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
-    err = S.emax >= (PJD_LUT_BADSIZE << 12) ? 1u : 0u;
+    err = (S.emax >= (PJD_LUT_BADSIZE << 12) || S.umin <= 14u) ? 1u : 0u;
     p = S.p;
     c = P.dus1 - ((S.ra - P.xbase) >> 4);
     z = 63u - (uint32_t)S.zb;
@@ -463,6 +465,13 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
 {
     const uint32_t l = threadIdx.x & 63;
     for (int iter = 0; iter < PJD_SYNC_MAX_ITERS; iter++) {
+#if PJD_TAIL_PRIO
+        // A wave that needs more than one round is a straggler: everything it still has to do (more rounds with few active lanes,
+        // the write pass) ends its picture's chain and, with batches in flight, the batch.  Let it issue ahead of the bulk work
+        // (first passes of other workgroups and other batches) that shares its SIMD.
+        if (iter == 1) __builtin_amdgcn_s_setprio(2);
+        if (iter == 4) __builtin_amdgcn_s_setprio(3);
+#endif
         uint32_t pp = __shfl_up(S.p_img, 1), pcz = __shfl_up(S.cz, 1), pch = __shfl_up(changed, 1);
         if (l == 0) { pp = ext_p; pcz = ext_cz; pch = (ext_new && iter == 0) ? 1u : 0u; }
         const bool act = g.valid && !g.seg_first && pch != 0;
@@ -619,6 +628,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     if (!wave_on) return;
 
     const uint64_t ts0 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    const uint64_t tc0 = B.dbg ? __builtin_amdgcn_s_memtime() : 0;          // shader clock: with ts0..ts5 (100 MHz) it gives the clock the chip held
     uint64_t *genA = B.wave_gen, *genB = B.wave_gen + B.n_hwave, *genC = B.wave_gen + 2 * (size_t)B.n_hwave;
     // ---- lane geometry
     LaneGeom g;
@@ -808,6 +818,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         uint32_t *d = B.dbg + (size_t)w * 32;
         d[0] = (uint32_t)ts0; d[1] = (uint32_t)(ts1 - ts0); d[2] = (uint32_t)(ts2 - ts1); d[3] = (uint32_t)(ts3 - ts2);
         d[4] = (uint32_t)(ts4 - ts3); d[5] = (uint32_t)(ts5 - ts4); d[6] = hw.image; d[7] = hw.n_lanes;
+        d[7] |= ((uint32_t)(((__builtin_amdgcn_s_memtime() - tc0) * 16) / ((ts5 - ts0) ? (ts5 - ts0) : 1)) & 0xffffffu) << 8;      // shader cycles per 10 ns, x16
     }
     if (dead) flag |= 1u << PJD_FLAG_TIMEOUT;
     // one status update and one counter per reason and wave

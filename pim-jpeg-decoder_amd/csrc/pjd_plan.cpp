@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 
@@ -343,6 +344,30 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         P.pixels += (uint64_t)d.width * d.height;
         P.ecs_bytes += d.ecs_len;
         P.out_bytes += h.out_bytes;
+    }
+    // Order of the Huffman workgroups = order in which they start (the kernel hands out indices by ticket).  Pictures whose stream
+    // is dense (many bytes per MCU) take the most re-sync rounds and finish last: start them first, so that their chains run beside
+    // the bulk of the batch instead of after it (matters with several batches in flight, when workgroups queue for a place on the
+    // chip).  Waves only wait for EARLIER waves of their own picture, so whole pictures can be moved freely; pictures that share a
+    // workgroup (same table set, consecutive waves) move together.
+    if (P.hwgs.size() > 1 && !std::getenv("PJD_KEEP_WG_ORDER")) {
+        struct Unit { size_t first, count; double key; };
+        std::vector<Unit> units;
+        auto density = [&](uint32_t img) { const PjdDevImage &g = P.images[img]; return g.n_mcu ? (double)g.ecs_len / (double)(g.last_mcu - g.first_mcu ? g.last_mcu - g.first_mcu : 1) : 0.0; };
+        for (size_t k = 0; k < P.hwgs.size(); k++) {
+            const PjdDevHuffWg &w = P.hwgs[k];
+            const uint32_t img_first = P.hwaves[w.first_wave].image, img_last = P.hwaves[w.first_wave + w.n_waves - 1].image;
+            double key = 0;
+            for (uint32_t im = img_first; im <= img_last; im++) key = std::max(key, density(im));
+            const bool joins = !units.empty() && P.hwaves[P.hwgs[k - 1].first_wave + P.hwgs[k - 1].n_waves - 1].image == img_first;
+            if (joins) { units.back().count++; units.back().key = std::max(units.back().key, key); }
+            else units.push_back({k, 1, key});
+        }
+        std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.key > b.key; });
+        std::vector<PjdDevHuffWg> ordered;
+        ordered.reserve(P.hwgs.size());
+        for (const Unit &u : units) ordered.insert(ordered.end(), P.hwgs.begin() + (long)u.first, P.hwgs.begin() + (long)(u.first + u.count));
+        P.hwgs.swap(ordered);
     }
     // the lane-word kernel copies PJD_WORD_ROWS words from every lane's first byte, whatever the lane's length
     P.ecs_buf_bytes = align_up(ecs_off + PJD_SUB_BYTES_MAX + 64, 256);
