@@ -493,7 +493,8 @@ int settle(pjd_batch *b)
         }
         PjdDevBatch dv = b->dev;
         dv.coef = coef;
-        hipError_t e = hipMemsetAsync(coef, 0, du * 64 * sizeof(int16_t), s);
+        pjd_launch_zero(s, coef, du * 64 * sizeof(int16_t));      // our own kernel, as everywhere on the decode path
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(d_list, fb.data(), fb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_base, fb_base.data(), fb_base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_wgs, fb_wgs.data(), fb_wgs.size() * sizeof(PjdDevIdctWg), hipMemcpyHostToDevice, s);

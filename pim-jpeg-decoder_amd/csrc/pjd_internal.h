@@ -30,6 +30,9 @@
 // per wave: the phase table -- one 16-byte record per data unit of the MCU: what the NEXT unit decodes with (table offsets,
 // its own record's address, the DC-sum selectors of its component); a unit's completion is one LDS read instead of ~9 VALU
 #define PJD_PHASE_LDS      256      // 16 records (an MCU has at most 4 + 2 = 6 units; sampling 2x2 with three components)
+#ifndef PJD_DIRECT_ECS
+#define PJD_DIRECT_ECS     0        // 1: the Huffman lanes read the batch's bitstream directly (unaligned dwords, byte-swapped) instead of the
+#endif                              //    transposed copy pjd_k_lane_words makes (experiment, profiles/r03_experiments.md)
 #ifndef PJD_TAIL_PRIO
 #define PJD_TAIL_PRIO      1        // waves in their second and later re-sync rounds raise their issue priority (s_setprio), see wave_rounds
 #endif

@@ -139,24 +139,34 @@ __global__ __launch_bounds__(256) void pjd_k_lane_words(PjdDevBatch B)
 // ---------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) uint8_t *pjd_gptr;      // global memory, so that loads are global_load (a generic
                                                                          // pointer gives flat_load, which also counts as an LDS access)
+#if PJD_DIRECT_ECS
+#define PJD_WORD_STRIDE 4u          // the lanes read the batch's bitstream itself: a lane's words are consecutive (unaligned) dwords
+#else
+#define PJD_WORD_STRIDE 256u        // transposed rows (pjd_k_lane_words): word k of a lane is 256 bytes after word k-1
+#endif
 struct BitWin {
-    pjd_gptr wb;          // wave-uniform: row 0 of the wave's word rows
+    pjd_gptr wb;          // wave-uniform: row 0 of the wave's word rows / the first byte of the picture's bitstream
     uint32_t hi, lo, nxt;
-    uint32_t off;         // byte offset (from wb) of this lane's word in the next row to fetch
+    uint32_t off;         // byte offset (from wb) of this lane's next word to fetch
     int s;
     __device__ __forceinline__ uint32_t word(uint32_t byte_off) const
     {
+#if PJD_DIRECT_ECS
+        return __builtin_bswap32(reinterpret_cast<const __attribute__((address_space(1))) UnalignedU32 *>(wb + byte_off)->v);
+#else
         return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(wb + byte_off);
+#endif
     }
-    __device__ __forceinline__ void init(pjd_gptr wave_words, uint32_t lane, uint32_t p)
+    // col = byte offset of the lane's word 0 from wb: lane * 4 in the transposed rows, the lane's first byte in the bitstream
+    __device__ __forceinline__ void init(pjd_gptr wave_words, uint32_t col, uint32_t p)
     {
         wb = wave_words;
         const int kk = (int)((p + 31) >> 5) - 1;          // word holding bit p-1 (or -1 at p == 0)
-        const uint32_t o = (uint32_t)(kk + 1) * 256 + lane * 4;
-        hi = kk >= 0 ? word(o - 256) : 0u;
+        const uint32_t o = (uint32_t)(kk + 1) * PJD_WORD_STRIDE + col;
+        hi = kk >= 0 ? word(o - PJD_WORD_STRIDE) : 0u;
         lo = word(o);
-        nxt = word(o + 256);
-        off = o + 512;
+        nxt = word(o + PJD_WORD_STRIDE);
+        off = o + 2 * PJD_WORD_STRIDE;
         s = 32 * (kk + 1) - (int)p;                        // 0..31
     }
     __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s); }
@@ -170,7 +180,7 @@ struct BitWin {
             // first waited for at the next refill (~7 symbols later), not here
             asm volatile("" : "+v"(hi), "+v"(lo));
             nxt = word(off);
-            off += 256;
+            off += PJD_WORD_STRIDE;
         }
     }
 };
@@ -262,7 +272,7 @@ __device__ __forceinline__ uint32_t add_flag(uint32_t v, bool f)
 // Inside the loop the slot is kept as zb = 63 - z (63: DC expected) and the phase as the LDS address of the unit's
 // phase record: one symbol is a table lookup, "zb -= advance", and three selects when the unit is complete.
 template <bool BRIDGE>
-__device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
+__device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col,
                                          uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                          uint32_t &ndu, const ChkCtx &K, uint32_t &jout)
 {
@@ -270,7 +280,7 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
     jout = 1;
     if (p >= end_bit) return SPAN_END;
     BitWin w;
-    w.init(wave_words, lane, p);
+    w.init(wave_words, col, p);
     uint32_t ra, x;
     {
         const uint2 cur = lds_u32x2(P.self(P.dus1 - c));
@@ -407,12 +417,12 @@ __device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState
 // Decodes from (p, c, z) until end_bit or until the segment's last data unit is complete (D == D_end).
 // Every active lane emits exactly one entry per step, so the entry count is the same in all of them and the
 // staging buffer is flushed by the whole wave at once.
-__device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t lane,
+__device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col,
                                            uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                            uint32_t &err, uint32_t &D, uint32_t D_end, OutCtx &O)
 {
     BitWin w;
-    w.init(wave_words, lane, p);
+    w.init(wave_words, col, p);
     WState S;
     S.p = p; S.zb = 63 - (int)z; S.emax = 0; S.umin = 0xffffffffu;
     {
@@ -449,7 +459,8 @@ struct LaneGeom {
     uint32_t end_bit;              // end of the subsequence, bits from the lane's first byte
     uint32_t seg_end_bit;          // end of the restart segment, same origin
     uint32_t base_bit;             // the lane's first byte, in bits relative to the image's ecs
-    pjd_gptr words;                // wave-uniform: row 0 of the wave's transposed word rows
+    pjd_gptr words;                // wave-uniform: row 0 of the wave's transposed word rows / the picture's bitstream
+    uint32_t col;                  // byte offset of the lane's word 0 from `words`
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pjd_huff_lds[];   // [tables][wave areas PJD_HUFF_WAVES x PJD_WAVE_LDS][phase tables PJD_HUFF_WAVES x PJD_PHASE_LDS][ticket]
@@ -482,7 +493,7 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
         changed = 0;
         if (act) {
             uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, j;
-            const int res = sync_span<true>(P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
+            const int res = sync_span<true>(P, g.words, g.col, p, c, z, g.end_bit, ndu, K, j);
             chk_finish(K, j, ndu);               // also after a merge: ndu then includes the units still to come
             S.cnt = ndu;
             if (res != SPAN_MERGED) {
@@ -636,7 +647,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     g.q = hw.first_lane + l;
     g.seg_first = g.seg_last = false;
     g.seg = 0; g.end_bit = g.seg_end_bit = g.base_bit = 0;
+#if PJD_DIRECT_ECS
+    g.words = (pjd_gptr)readfirstlane_u64((uint64_t)(B.ecs + im.ecs_off));
+    g.col = 0;
+#else
     g.words = (pjd_gptr)readfirstlane_u64((uint64_t)(B.words + (size_t)w * B.word_rows * 64));
+    g.col = l * 4;
+#endif
     uint32_t seg_first_du = 0, seg_n_du = 0;
     const uint32_t sub_bytes = rfl(im.sub_bytes);        // of this wave's image
     if (g.valid) {
@@ -647,6 +664,9 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         const uint32_t end_byte = sb.byte_start + sub_bytes < sg.byte_end ? sb.byte_start + sub_bytes : sg.byte_end;
         g.seg_last = end_byte == sg.byte_end;
         g.base_bit = sb.byte_start * 8;
+#if PJD_DIRECT_ECS
+        g.col = sb.byte_start;
+#endif
         g.end_bit = (end_byte - sb.byte_start) * 8;
         g.seg_end_bit = (sg.byte_end - sb.byte_start) * 8;
         seg_first_du = sg.first_du; seg_n_du = sg.n_du;
@@ -667,7 +687,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     {
         uint32_t p = 0, c = 0, z = 0, ndu = 0, j = 1;
         if (g.valid) {
-            sync_span<false>(P, g.words, l, p, c, z, g.end_bit, ndu, K, j);
+            sync_span<false>(P, g.words, g.col, p, c, z, g.end_bit, ndu, K, j);
             chk_finish(K, j, ndu);
         }
         S.p_img = p + g.base_bit; S.cz = (c << 8) | z; S.cnt = ndu;
@@ -791,7 +811,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 O.left = first_du + k * O.ru - D_in;
             }
             uint32_t err = 0;
-            write_span(P, g.words, l, p, c, z, g.end_bit, err, D, D_end, O);
+            write_span(P, g.words, g.col, p, c, z, g.end_bit, err, D, D_end, O);
             li.n_ent = O.n;
             li.dc_sum[0] = (uint16_t)O.dcA; li.dc_sum[1] = (uint16_t)(O.dcA >> 16); li.dc_sum[2] = (uint16_t)O.dcB;
             if (err) flag |= 1u << PJD_FLAG_SYMBOL;
@@ -846,6 +866,9 @@ void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b)
 }
 void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b)
 {
+#if PJD_DIRECT_ECS
+    return;
+#endif
     if (b.n_hwave) hipLaunchKernelGGL(pjd_k_lane_words, dim3(b.n_hwave), dim3(256), 0, s, b);
 }
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b)
