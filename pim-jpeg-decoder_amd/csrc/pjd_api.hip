@@ -321,6 +321,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.marks, P.iwgs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.out, P.out_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
+    TRY_RC(dev_alloc(ctx, b->dev.imstate, (size_t)n_images, tot));
     // wave_gen [3][n_hwave], wave_desc [n_hwave] and the ticket live in one allocation, zeroed before every launch
     TRY_RC(dev_alloc(ctx, b->d_opstate, n_hwave * 4 + 2, tot));
     b->opstate_bytes = (n_hwave * 4 + 2) * sizeof(uint64_t);

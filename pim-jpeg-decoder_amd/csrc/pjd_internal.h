@@ -78,9 +78,26 @@
 #define PJD_IF_SEQUENTIAL       2u  // routed to the exact one-lane kernel up front
 #define PJD_IF_BMP              4u  // output is a BMP file image (else tight RGB8)
 #define PJD_IF_STANDARD_ZIGZAG  8u  // zigzag slot 48 -> natural 58, no slot-52 override (PJD_F_STANDARD_ZIGZAG)
+#define PJD_IF_ENDS_STREAM      16u // the last restart segment this image (or shard) decodes is the last of its bitstream: running out of
+                                    // bits there is the reference's end-of-data error, handled by the parallel decoder itself
 
 // status word per image: low 8 bits = PJD_ST_* class, bit 8 = "fast path gave up, needs exact kernel"
 #define PJD_STW_NEEDS_EXACT 0x100
+
+// What the parallel decoder found wrong in an image, kept per image and ordered by POSITION in the stream (PjdDevBatch::imstate):
+//   err_key   the first entropy-coding error of the true decode (the reference stops there, jpeg_scanner.cpp:470-514; everything
+//             decoded before it is kept, the rest of the picture stays undecoded): minimum over the lanes that met one of
+//             (bit position of the offending symbol << 32) | (index of its data unit << 4) | (PJD_ST_* class << 1 ... see below);
+//             the write pass finds it by itself -- bad symbol, bad size, run past slot 63, end of data -- so such pictures
+//             need no second decode
+//   flag_pos  bit position (start of the lane, or of the wave's first lane) of the earliest thing the decoder could NOT resolve
+//             (PJD_FLAG_*): only that, and only if it lies before the first error, sends the picture to the exact kernel
+// layout of err_key's low word: bits 31..4 data unit, bits 3..1 PJD_ST_* class, bit 0 = the error is in the unit's DC symbol
+struct PjdDevImState {
+    unsigned long long err_key;        // ~0: none
+    uint32_t flag_pos;                 // ~0: none
+    uint32_t pad_;
+};
 
 // why the parallel decoder flagged an image (PjdDevBatch::stats[PJD_STAT_FLAG0 + reason], counted per wave)
 enum {
@@ -143,8 +160,10 @@ struct PjdDevHuffRaw {
 //               more than any unit has left -- so "63 - slot" minus that number going negative is "the unit is complete";
 //               a run/size symbol that lands past slot 63 (an error in the reference, jpeg_scanner.cpp:500) leaves -16..-2 there,
 //               an EOB -97..-35, a unit that ends exactly on slot 63 leaves -1: the write pass tells them apart with one minimum
-//   bits 15..12 value bits (size) 0..11; 15 = invalid: no code starts with these bits (then 16 bits are consumed, as the
-//               reference's get_next_symbol does), a DC size > 11 or an AC size > 10 (the code alone is consumed)
+//   bits 15..12 value bits (size) 0..11, or an invalid symbol (the code alone is consumed):
+//               14 = the reference's "symbol 0xFF": no code starts with these bits (then 16 bits are consumed, as its
+//                    get_next_symbol does), or the table really holds the symbol 0xFF (jpeg_scanner.cpp:470,490)
+//               15 = a DC size > 11 / an AC size > 10 (jpeg_scanner.cpp:474,506)
 //   pointer entry (bits 4..0 == 0): codes with this 10-bit prefix are longer than 10 bits; bits 15..5 = u16 index (relative to the
 //               blob) / 64 of the prefix's 64-entry second-level table, indexed by the following 6 bits; entries there have the
 //               first form with code lengths 11..16.
@@ -162,7 +181,8 @@ struct PjdDevTset {
 #define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 97 for an EOB
 #define PJD_LUT_SIZE(e)  ((e) >> 12)              // of a 16-bit entry
 #define PJD_LUT_EOB      0x0800u
-#define PJD_LUT_BADSIZE  15u
+#define PJD_LUT_BADSYM   14u
+#define PJD_LUT_BADLEN   15u
 #define PJD_LUT_ENTRY(used, adv, eob, size)  ((used) | ((adv) << 5) | ((eob) ? PJD_LUT_EOB : 0u) | ((size) << 12))
 
 struct PjdDevSegment {                 // one restart segment

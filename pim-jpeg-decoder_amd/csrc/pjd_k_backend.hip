@@ -112,7 +112,11 @@ __global__ __launch_bounds__(256) void pjd_k_reset(PjdDevBatch B, const int32_t 
                                                    uint32_t opstate_words, uint32_t dbg_words)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < B.n_images) B.status[i] = status_init[i];
+    if (i < B.n_images) {
+        B.status[i] = status_init[i];
+        PjdDevImState st; st.err_key = ~0ull; st.flag_pos = 0xffffffffu; st.pad_ = 0;
+        B.imstate[i] = st;
+    }
     if (i < 16) B.stats[i] = 0;
     if (i < opstate_words) opstate[i] = 0;
     for (uint32_t k = i; k < dbg_words; k += gridDim.x * 256) B.dbg[k] = 0;
@@ -150,6 +154,34 @@ void pjd_launch_dpu_payload(hipStream_t s, const uint32_t *metadata, int16_t *mc
 // blocks of PJD_DC_BLOCK lanes, then one workgroup over the block aggregates.  The back end adds
 // the block's carry-in itself.  All sums are modulo 2^16 like the reference's `short` stores.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Per-picture verdict of the parallel entropy decode (after pjd_k_huff_lanes, before the back end): the first entropy-coding
+// error of the true decode gives the status word -- the reference's error class; its picture keeps what was decoded before the
+// error (reference src/decoder_host.cpp:181 ignores the failure and writes the picture) -- unless something the decoder could
+// not resolve lies at or before it: then, and for any unresolved thing in a picture without an error, the exact kernel decodes it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pjd_k_image_verdict(PjdDevBatch B)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B.n_images) return;
+    const int32_t st = B.status[i];
+    if (st & PJD_STW_NEEDS_EXACT) return;                       // routed to the exact kernel up front
+    const PjdDevImState s = B.imstate[i];
+    const bool has_err = s.err_key != ~0ull;
+    const uint32_t err_pos = (uint32_t)(s.err_key >> 32);
+    if (s.flag_pos != 0xffffffffu && (!has_err || s.flag_pos <= err_pos)) B.status[i] = st | PJD_STW_NEEDS_EXACT;
+    else if (has_err) B.status[i] = (int32_t)((s.err_key >> 1) & 7u);
+}
+
+// Data units of a range [first_du, first_du + n_du) the back end materialises: all of them, or those up to the picture's first
+// entropy-coding error (the unit that holds it included, unless the error is in its DC symbol: pjd_internal.h, PjdDevImState).
+__device__ __forceinline__ uint32_t pjd_units_decoded(unsigned long long err_key, uint32_t first_du, uint32_t n_du)
+{
+    if (err_key == ~0ull) return n_du;
+    const uint32_t stop = (uint32_t)((err_key >> 4) & 0x0fffffffu) + ((err_key & 1u) ? 0u : 1u);
+    return stop <= first_du ? 0u : (stop - first_du < n_du ? stop - first_du : n_du);
+}
+
 __global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_lane_dc_local(PjdDevBatch B)
 {
     __shared__ uint32_t sy[PJD_DC_BLOCK], scb[PJD_DC_BLOCK], scr[PJD_DC_BLOCK], sf[PJD_DC_BLOCK];
@@ -616,10 +648,14 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         comp_of[tid] = (uint8_t)(kk < nl ? 0 : kk - nl + 1);
     }
 
+    // units of this range that were decoded: all, unless the picture's first entropy-coding error lies in or before the range (the
+    // others keep zero coefficients, as in the reference, whose buffers start zeroed and which stops at the error)
+    const uint32_t n_valid = pjd_units_decoded(B.imstate[wg.image].err_key, wg.first_mcu * dus, n_du);
     const PjdDevMark mark = B.marks[blockIdx.x];
     const uint32_t lane_end = im.lane_base + im.n_lane;
     uint32_t q = mark.lane, n = mark.ent_off;
-    if (q < im.lane_base || q >= lane_end) return;              // never on a verified image; keeps a stale mark harmless
+    if (n_valid == 0) { q = im.lane_base; n = 0; }              // nothing to parse: the mark may never have been written
+    else if (q < im.lane_base || q >= lane_end) return;         // never on a verified image; keeps a stale mark harmless
     // predictors at the first unit: lane start (block-relative or absolute) + block carry + sums inside the lane
     uint32_t pred0[3];
     {
@@ -635,7 +671,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     // before it (a DC entry counts 1), M = A at the start of its unit; zigzag slot = A - M + run.  U and A come from one
     // additive scan, M from a max scan (A never decreases).
     uint32_t run_units = 0, run_tail = 0;                       // over the chunks so far (uniform): units done, A - M at the chunk start
-    for (uint32_t it = 0; run_units < n_du; ) {
+    for (uint32_t it = 0; run_units < n_valid; ) {
         if (n >= n_ent) {                                       // next lane of the image
             q++; n = 0;
             if (q >= lane_end) break;
@@ -702,7 +738,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         uint32_t u = run_units + (exc >> 16), a_pos = exc & 0xffffu;
 #pragma unroll
         for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
-            if (i0 + k < cnt && u < n_du) {
+            if (i0 + k < cnt && u < n_valid) {
                 if (isdc[k]) dcraw[u] = (int)(((e[k] & 0x7ffu) | ((e[k] >> 1) & 0x800u)) << 20) >> 20;
                 else {
                     const int val = (int)(e[k] << 21) >> 21;
@@ -749,7 +785,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         uint32_t cy = pred0[0], cc = (pred0[1] & 0xffffu) | (pred0[2] << 16);   // predictors entering the next group of 64 units
         for (uint32_t base = 0; base < n_du; base += 64) {
             const uint32_t u = base + lane;
-            const bool on = u < n_du;
+            const bool on = u < n_valid;                        // an undecoded unit keeps DC 0: it is never predicted
             const uint32_t d = d0 + u, m = d / dus, kk = d - m * dus, comp = kk < nl ? 0 : kk - nl + 1;
             const uint32_t dv = on ? (uint32_t)dcraw[on ? u : 0] & 0xffffu : 0u;
             const bool head = on && kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
@@ -803,6 +839,7 @@ void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b)
 void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b)
 {
     if (b.n_dcblk == 0) return;
+    hipLaunchKernelGGL(pjd_k_image_verdict, dim3((b.n_images + 255) / 256), dim3(256), 0, s, b);
     hipLaunchKernelGGL(pjd_k_lane_dc_local, dim3(b.n_dcblk), dim3(PJD_DC_BLOCK), 0, s, b);
     hipLaunchKernelGGL(pjd_k_lane_dc_carry, dim3(1), dim3(256), 0, s, b);
 }

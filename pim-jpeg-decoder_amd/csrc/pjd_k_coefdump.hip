@@ -53,7 +53,15 @@ __global__ __launch_bounds__(64) void pjd_k_coefdump_lanes(PjdDevBatch B, uint32
     }
     uint32_t n_ent = B.lane_info[q].n_ent;
     uint32_t D = wg.first_mcu * dus;
-    const uint32_t D_stop = D + wg.n_mcu * dus;
+    uint32_t D_stop = D + wg.n_mcu * dus;
+    {   // nothing behind the picture's first entropy-coding error was decoded (PjdDevImState)
+        const unsigned long long key = B.imstate[image].err_key;
+        if (key != ~0ull) {
+            const uint32_t stop = (uint32_t)((key >> 4) & 0x0fffffffu) + ((key & 1u) ? 0u : 1u);
+            if (stop < D_stop) D_stop = stop;
+        }
+    }
+    if (D >= D_stop) return;
     uint32_t slot = 0, comp = 0;
     size_t base = 0;
     bool in_unit = false;

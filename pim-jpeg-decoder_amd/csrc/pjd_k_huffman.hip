@@ -42,28 +42,30 @@
 
 #include "pjd_device_common.h"
 #include "pjd_kernels.h"
+#include "../../include/pjd.h"
 
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
 static_assert(PJD_LUT_BITS == 10, "second level is indexed by the 6 bits after a 10-bit prefix");
 static_assert(PJD_HUFF_LANES == 64, "one wave per 64 lanes");
 
-#define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSIZE)   // no code: consume 16 bits (as the reference's get_next_symbol)
+#define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSYM)    // no code: consume 16 bits (as the reference's get_next_symbol)
 
 // ---------------------------------------------------------------------------------------------
 // One block per (table set, table slot): two-level decode table (layout: pjd_internal.h).
 __device__ __forceinline__ uint32_t lut_entry(uint32_t len, uint32_t sym, bool is_ac)
 {
-    uint32_t run = 0, size;
-    bool eob = false, bad = false;
+    uint32_t run = 0, size, bad = 0;
+    bool eob = false;
+    if (sym == 0xFF) bad = PJD_LUT_BADSYM;                              // the reference reads a returned 0xFF as "no symbol" (jpeg_scanner.cpp:470,490)
     if (is_ac) {
         run = sym >> 4; size = sym & 15u;
         if (sym == 0) eob = true;
-        else if (size > 10) bad = true;                                 // jpeg_scanner.cpp:506
+        else if (size > 10 && !bad) bad = PJD_LUT_BADLEN;               // jpeg_scanner.cpp:506
     } else {
         size = sym;
-        if (sym > 11) bad = true;                                       // jpeg_scanner.cpp:474
+        if (sym > 11 && !bad) bad = PJD_LUT_BADLEN;                     // jpeg_scanner.cpp:474
     }
-    return PJD_LUT_ENTRY(len + (bad ? 0u : size), eob ? 33u : run + 1, eob, bad ? PJD_LUT_BADSIZE : size);   // EOB: 33 + 64 = 97 slots (pjd_internal.h)
+    return PJD_LUT_ENTRY(len + (bad ? 0u : size), eob ? 33u : run + 1, eob, bad ? bad : size);   // EOB: 33 + 64 = 97 slots (pjd_internal.h)
 }
 
 __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
@@ -359,7 +361,7 @@ struct WState {            // decoder state of the write pass, in registers
     int zb;                // 63 - zigzag slot
     uint32_t ra, x;        // phase record address, table offsets of the current unit
     uint32_t mA, mB;       // DC-sum selectors of the current unit's component
-    uint32_t emax;         // max over the table entries seen: >= 0xf000 <=> an invalid symbol (size field 15)
+    uint32_t emax;         // max over the table entries seen: >= 0xe000 <=> an invalid symbol (size field 14 or 15)
     uint32_t umin;         // min over the symbols of (63 - slot after the symbol) + 16, unsigned: <= 14 <=> a run past slot 63
 };
 
@@ -443,10 +445,74 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
         }
     }
     if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
-    err = (S.emax >= (PJD_LUT_BADSIZE << 12) || S.umin <= 14u) ? 1u : 0u;
+    err = (S.emax >= (PJD_LUT_BADSYM << 12) || S.umin <= 14u) ? 1u : 0u;
     p = S.p;
     c = P.dus1 - ((S.ra - P.xbase) >> 4);
     z = 63u - (uint32_t)S.zb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The CAREFUL write pass of one lane: run again, symbol by symbol with every check of the reference in the reference's order,
+// for a lane whose fast pass saw something invalid (bad symbol or size, run past slot 63) or that reaches the end of the
+// bitstream before the picture is complete.  It stops AT the offending symbol exactly as decode_MCU_component does
+// (reference src/jpeg_scanner.cpp:469-518): nothing of that symbol is stored, everything before it is; an error inside a unit's
+// AC part leaves the unit with what it has (closed here by an end-of-block entry), an error in the DC symbol leaves the unit
+// untouched.  Rare by construction, so entries go straight to HBM two bytes at a time.
+//   eof_rel: bits from the lane's first byte to the end of the stream, or ~0 if the stream does not end in this lane's segment:
+//            running out of bits is get_next_symbol's 0xFF / read_bits' -1 (reference src/headers/jpeg.h:91-113)
+struct Careful {
+    uint32_t n;            // entries written
+    uint32_t cls;          // PJD_ST_* of the error, 0: none found
+    uint32_t p_err, D_err, in_dc;
+    uint32_t dcA, dcB;
+};
+
+__device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col, uint32_t p, uint32_t c, uint32_t z,
+                                          uint32_t end_bit, uint32_t eof_rel, uint32_t D, uint32_t D_end, uint16_t *region, uint32_t cap, Careful &R)
+{
+    BitWin w;
+    w.init(wave_words, col, p);
+    uint4 cur = lds_u32x4(P.self(P.dus1 - c));      // .x tables, .y own record, .z / .w DC-sum selectors of the current unit
+    int zb = 63 - (int)z;
+    R.n = 0; R.cls = 0; R.p_err = 0; R.D_err = 0; R.in_dc = 0; R.dcA = 0; R.dcB = 0;
+    const bool at_end = eof_rel != 0xffffffffu;
+    while (D < D_end && (p < end_bit || at_end)) {
+        const bool is_dc = zb == 63;
+        const uint32_t pk = w.peek();
+        const uint4 nx = lds_u32x4(cur.y);
+        const uint32_t e = lut_lookup(P.lbase, is_dc ? (cur.x & 0xffffu) : (cur.x >> 16), pk);
+        const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e), adv = PJD_LUT_ADV(e);
+        const uint32_t vbits = size >= PJD_LUT_BADSYM ? 0u : size, codelen = used - vbits;
+        const uint32_t left = !at_end ? 64u : (eof_rel > p ? eof_rel - p : 0u);
+        uint32_t bad = 0;
+        if (size == PJD_LUT_BADSYM || codelen > left) bad = is_dc ? PJD_ST_DC_SYM : PJD_ST_AC_SYM;           // :470 / :490
+        else if (is_dc) {
+            if (size == PJD_LUT_BADLEN) bad = PJD_ST_DC_LEN;                                                    // :474
+            else if (vbits > left - codelen) bad = PJD_ST_DC_BITS;                                              // :480
+        } else if (!(e & PJD_LUT_EOB)) {
+            if (zb - (int)adv <= -2) bad = PJD_ST_AC_RUN;                                                       // :500
+            else if (size == PJD_LUT_BADLEN) bad = PJD_ST_AC_LEN;                                               // :506
+            else if (vbits > left - codelen) bad = PJD_ST_AC_BITS;                                              // :512
+        }
+        if (bad) {
+            R.cls = bad; R.p_err = p; R.D_err = D; R.in_dc = is_dc ? 1u : 0u;
+            if (!is_dc && R.n < cap) region[R.n++] = (uint16_t)PJD_ENT_LAST;       // the unit keeps what it has
+            break;
+        }
+        const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size);
+        const uint32_t m1 = 1u << size;
+        const int val = (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
+        w.drop(used);
+        p += used;
+        zb -= (int)adv;
+        const bool done = zb < 0;
+        const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : ((adv - 1u) & 15u);
+        if (R.n < cap) region[R.n++] = (uint16_t)(((uint32_t)val & 0x7ffu) | (top << 12) | (done ? PJD_ENT_LAST : 0u));
+        const uint32_t dv = is_dc ? ((uint32_t)val & 0xffffu) : 0u, dvv = dv | (dv << 16);
+        R.dcA = pk_add16(R.dcA, dvv & cur.z);
+        R.dcB = pk_add16(R.dcB, dvv & cur.w);
+        if (done) { zb = 63; cur = nx; D++; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -811,19 +877,38 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 O.left = first_du + k * O.ru - D_in;
             }
             uint32_t err = 0;
+            const uint32_t p0 = p, c0 = c, z0 = z;
             write_span(P, g.words, g.col, p, c, z, g.end_bit, err, D, D_end, O);
             li.n_ent = O.n;
             li.dc_sum[0] = (uint16_t)O.dcA; li.dc_sum[1] = (uint16_t)(O.dcA >> 16); li.dc_sum[2] = (uint16_t)O.dcB;
-            if (err) flag |= 1u << PJD_FLAG_SYMBOL;
-            if (O.overflow) flag |= 1u << PJD_FLAG_OVERFLOW;
-            if (D == D_end) {
-                if (p > g.seg_end_bit) flag |= 1u << PJD_FLAG_SEGMENT;
-                const bool has_next = g.seg + 1 < im.seg_base + im.n_seg;
-                if (has_next && ((p + 7) & ~7u) != g.seg_end_bit) flag |= 1u << PJD_FLAG_SEGMENT;
-            } else {
-                if (S.p_img - g.base_bit != p || (S.cz >> 8) != c || (S.cz & 255) != z) flag |= 1u << PJD_FLAG_VERIFY;
-                if (D - D_in != S.cnt) flag |= 1u << PJD_FLAG_VERIFY;
-                if (g.seg_last) flag |= 1u << PJD_FLAG_SEGMENT;
+            const bool has_next = g.seg + 1 < im.seg_base + im.n_seg;
+            // the lane in which the bitstream ends: too few bits for the picture is the reference's end-of-data error, not ours
+            const bool eof_lane = g.seg_last && !has_next && (im.flags & PJD_IF_ENDS_STREAM) != 0;
+            bool settled = false;
+            if (err || (eof_lane && (D < D_end || p > g.seg_end_bit))) {
+                // an entropy-coding error of the TRUE decode (this lane started from the true state): find it exactly, keep what
+                // precedes it, report it by position -- the picture's verdict takes the first one (pjd_k_image_verdict)
+                Careful R;
+                careful_span(P, g.words, g.col, p0, c0, z0, g.end_bit, eof_lane ? g.seg_end_bit : 0xffffffffu, D_in, D_end, O.region, O.cap, R);
+                if (R.cls) {
+                    li.n_ent = R.n;
+                    li.dc_sum[0] = (uint16_t)R.dcA; li.dc_sum[1] = (uint16_t)(R.dcA >> 16); li.dc_sum[2] = (uint16_t)R.dcB;
+                    const unsigned long long key = ((unsigned long long)(g.base_bit + R.p_err) << 32) | ((unsigned long long)R.D_err << 4) | (R.cls << 1) | R.in_dc;
+                    atomicMin(&B.imstate[hw.image].err_key, key);
+                    settled = true;
+                }
+            }
+            if (!settled) {
+                if (err) flag |= 1u << PJD_FLAG_SYMBOL;
+                if (O.overflow) flag |= 1u << PJD_FLAG_OVERFLOW;
+                if (D == D_end) {
+                    if (p > g.seg_end_bit) flag |= 1u << PJD_FLAG_SEGMENT;
+                    if (has_next && ((p + 7) & ~7u) != g.seg_end_bit) flag |= 1u << PJD_FLAG_SEGMENT;
+                } else {
+                    if (S.p_img - g.base_bit != p || (S.cz >> 8) != c || (S.cz & 255) != z) flag |= 1u << PJD_FLAG_VERIFY;
+                    if (D - D_in != S.cnt) flag |= 1u << PJD_FLAG_VERIFY;
+                    if (g.seg_last) flag |= 1u << PJD_FLAG_SEGMENT;
+                }
             }
         }
     }
@@ -841,12 +926,19 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         d[7] |= ((uint32_t)(((__builtin_amdgcn_s_memtime() - tc0) * 16) / ((ts5 - ts0) ? (ts5 - ts0) : 1)) & 0xffffffu) << 8;      // shader cycles per 10 ns, x16
     }
     if (dead) flag |= 1u << PJD_FLAG_TIMEOUT;
-    // one status update and one counter per reason and wave
-    uint32_t wflag = flag, went = g.valid ? li.n_ent : 0;
-    for (int off = 1; off < 64; off <<= 1) { wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off); }
+    // per wave: one counter per reason, and WHERE in the picture's stream the earliest unresolved thing lies (the start of the
+    // flagged lane; conditions that concern the whole wave flag every lane, i.e. the wave's first).  Whether that sends the picture
+    // to the exact kernel is decided per picture once all its waves have reported (pjd_k_image_verdict): what lies behind the
+    // picture's first entropy-coding error is never decoded by the reference and does not count.
+    uint32_t wflag = flag, went = g.valid ? li.n_ent : 0, wpos = (flag && g.valid) ? g.base_bit : 0xffffffffu;
+    for (int off = 1; off < 64; off <<= 1) {
+        wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off);
+        const uint32_t o = __shfl_xor(wpos, off);
+        wpos = o < wpos ? o : wpos;
+    }
     if (l == 0) atomicAdd(B.stats + PJD_STAT_ENTRIES, (unsigned long long)went);
     if (wflag && l == 0) {
-        atomicOr(reinterpret_cast<unsigned int *>(B.status + hw.image), PJD_STW_NEEDS_EXACT);
+        atomicMin(&B.imstate[hw.image].flag_pos, wpos);
         for (int r = 0; r < PJD_FLAG_REASONS; r++)
             if (wflag & (1u << r)) atomicAdd(B.stats + PJD_STAT_FLAG0 + r, 1ull);
     }

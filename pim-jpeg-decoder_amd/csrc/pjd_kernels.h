@@ -27,6 +27,7 @@ struct PjdDevBatch {
     PjdDevMark *marks;                   // per IDCT workgroup of the parallel path
     uint8_t *out;
     int32_t *status;                     // per image
+    PjdDevImState *imstate;              // per image: first entropy-coding error / earliest unresolved irregularity of this decode
     // Huffman kernel scratch (zeroed before every launch)
     uint64_t *wave_gen;                  // [3][n_hwave]: exit state of a wave's last lane | flag; generations A / B / C
     uint64_t *wave_desc;                 // per Huffman wave: look-back descriptor (status | poison | head | units)
@@ -49,7 +50,7 @@ void pjd_launch_copy_out(hipStream_t s, const void *src, void *dst_mapped, uint6
 // dense input (exact path): wgs[k].pad_ = index into dense_base[] (data unit 0 of that image's scratch)
 void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, const uint64_t *dense_base, uint32_t n_wg);
 void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b);                                     // lane-stream input
-void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b);      // two kernels: local scan + carry
+void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b);      // three kernels: per-image verdict (status words), local scan, carry
 // ---- stage-level parity (pjd_k_coefdump.hip): coefficients in the reference's MCU_buffer layout; `out` is zeroed by the caller
 void pjd_launch_coefdump_lanes(hipStream_t s, const PjdDevBatch &b, uint32_t image, uint32_t n_iwg, int16_t *out);
 void pjd_launch_coefdump_dense(hipStream_t s, const PjdDevBatch &b, uint32_t image, const int16_t *scratch, uint32_t first_du, uint32_t n_du, int16_t *out);

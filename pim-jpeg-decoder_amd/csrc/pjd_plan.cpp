@@ -238,6 +238,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             byte_lo = d.seg_offsets[seg_lo];
             byte_hi = (seg_hi < nseg_total) ? d.seg_offsets[seg_hi] : d.ecs_len;
         }
+        if (seg_hi == nseg_total) g.flags |= PJD_IF_ENDS_STREAM;   // this image (or shard) decodes the bitstream's last segment
         g.first_mcu = (RI != 0 && !sequential) ? seg_lo * RI : 0;
         g.last_mcu = (RI != 0 && !sequential && seg_hi < nseg_total) ? seg_hi * RI : g.n_mcu;
 

@@ -169,10 +169,11 @@ def test_cli_writes_reference_bmps(tmp_path):
 
 
 def test_routing_parallel_path_is_the_one_that_runs(ctx):
-    """Regular streams must be decoded by the parallel kernels (no silent exact-kernel fallback);
-    broken streams must be re-decoded by the exact kernel."""
+    """Regular streams must be decoded by the parallel kernels (no silent exact-kernel fallback); so must streams with an
+    entropy-coding error or a missing tail (the write pass finds the reference's error itself); only what the parallel decoder
+    cannot reproduce -- the reference's restart rule with subsampled luma, tables it does not take -- goes to the exact kernel."""
     import pjd_amd
-    expect_fallback = {"err_corrupt_3", "err_truncated_eoi_420", "err_truncated_eoi_444"}
+    expect_fallback = set()      # round 3: entropy-coding errors and truncated streams are settled by the parallel decoder itself
     for name in VALID:
         s = _desc(name)
         with ctx.batch([s.desc]) as b:
@@ -913,3 +914,49 @@ def test_cli_split_writes_the_same_bmp(tmp_path, monkeypatch):
             assert not bmp.exists()
         else:
             assert hashlib.sha256(bmp.read_bytes()).hexdigest() == ent["bmp_sha256"], n
+
+
+# ---- the exact-kernel cliff: broken big pictures must not fall onto the one-lane kernel ---------------------------------------
+def test_corrupt_and_truncated_4k_pictures_settle_on_the_parallel_path(ctx, port):
+    """A 3840x2160 picture (2 MB of entropy-coded data) with (a) the stream cut in the middle, (b) a few bytes overwritten at
+    one third, (c) both: the reference reports an error and keeps what it decoded before it (src/decoder_host.cpp:181).  The
+    parallel decoder settles all of them itself -- same status, same partial picture, same coefficients as the oracle -- without the
+    one-lane exact kernel (which needs about a second for such a stream), in well under 100 ms per picture."""
+    import time
+    import pjd_amd
+    synth = _synth()
+    good = synth.cfg2_single_4k(seed=2)
+    sos = good.rfind(b"\xff\xda")
+    body = sos + 14
+    n = len(good) - 2 - body
+    cut = good[:body + n // 2] + b"\xff\xd9"
+    ba = bytearray(good)
+    k = body + n // 3
+    for j in range(4):
+        if ba[k + j] != 0xFF and ba[k + j - 1] != 0xFF:
+            ba[k + j] ^= 0x5A
+            if ba[k + j] == 0xFF:
+                ba[k + j] = 0x7F
+    both = bytes(ba[:body + (2 * n) // 3]) + b"\xff\xd9"
+    cases = {"truncated": cut, "corrupted": bytes(ba), "corrupted + truncated": both}
+    n_err = 0
+    for label, data in cases.items():
+        s = pjd_amd.Scanned(data)
+        assert s.valid, label
+        want = port.decode(data)
+        with ctx.batch([s.desc]) as b:
+            b.upload()
+            b.decode(); b.sync()                      # warm (allocations, first launch)
+            t0 = time.perf_counter()
+            b.decode(); b.sync()
+            dt = time.perf_counter() - t0
+            outs, st = b.download()
+            info = b.info()
+            coef = b.coefficients(0)
+        assert st[0] == want["huff_rc"], (label, st[0], want["huff_rc"])
+        assert np.array_equal(outs[0], want["rgb"]), label
+        assert np.array_equal(coef, want["coef"]), label
+        assert info["n_sequential"] == 0 and info["n_fallback"] == 0, (label, info["flag_waves"])
+        assert dt < 0.1, (label, dt)
+        n_err += st[0] != 0
+    assert n_err >= 2          # the cut always ends in the reference's end-of-data error; the overwrite may re-synchronise cleanly
