@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4,
                     help="resident batches decoded round-robin, each on its own HIP stream: step i is issued while step i-1 is "
                          "still running, as a serving loop would (1 = strictly one step after the other)")
+    ap.add_argument("--force-exact", action="store_true",
+                    help="decode everything with the exact one-lane kernel (PJD_F_FORCE_SEQUENTIAL): the bound of the fallback path, not a product mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurement on the lighter cfg3lite set")
     ap.add_argument("--out-format", default="bmp", choices=["bmp", "rgb8"],
@@ -235,10 +237,13 @@ def main():
             label += f"; split by restart segment over {world} ranks (descriptor blob {blob_bytes} B broadcast)"
         else:
             descs = [s.desc for s in scanned]
+        if args.force_exact:
+            for s in scanned:
+                s.desc.flags = int(s.desc.flags) | pjd_amd.F_FORCE_SEQUENTIAL
         if workload == "cfg2rst":
             # 4:2:0 + DRI: the reference's own restart rule garbles such files; decode per ITU-T.81
             for s in scanned:
-                s.desc.flags = pjd_amd.F_STANDARD_RESTART
+                s.desc.flags = int(s.desc.flags) | pjd_amd.F_STANDARD_RESTART
         # One context = one HIP stream.  `--in-flight` identical batches are resident; step i decodes batch i % in_flight,
         # so consecutive steps overlap (the slow tail of one step's entropy decode runs beside the next step's bulk).
         ctxs = [pjd_amd.Context(local_rank) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing

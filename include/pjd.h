@@ -147,7 +147,12 @@ typedef struct pjd_batch_info {
     uint32_t n_table_sets;             /* distinct Huffman table sets (images with identical tables share one) */
     uint64_t n_huff_waves;
     uint64_t n_entries;                /* 16-bit coefficient entries (= Huffman symbols) emitted by the last decode */
-    uint64_t flag_waves[8];            /* waves that sent their image to the exact kernel in the last decode, by reason:
+    float    exact_fallback_ms;        /* GPU time (HIP events) the exact one-lane kernel + its back end took to re-decode the
+                                          pictures the parallel decoder could not resolve in the last decode; 0 if none.  The exact
+                                          kernel is a single dependent chain per picture: about 10 MPix/s per picture */
+    uint32_t n_entropy_errors;         /* pictures of the last decode with an entropy-coding error (status != 0) that the parallel
+                                          decoder settled itself                                                               */
+    uint64_t flag_waves[8];            /* waves that reported something unresolved in the last decode, by reason:
                                           0 invalid symbol, 1 irregular segment end / phase, 2 re-sync did not converge,
                                           3 wave boundary did not stitch, 4 wait timed out, 5 lane output overflow,
                                           6 write pass did not reproduce the synchronised state                     */

@@ -154,6 +154,8 @@ struct pjd_batch {
     uint64_t device_bytes = 0;
     bool uploaded = false, decoded = false, settled = false;
     int n_fallback = 0;
+    float exact_fallback_ms = 0;
+    uint32_t n_entropy_errors = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
 };
@@ -417,8 +419,8 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
     pjd_launch_reset(s, b->dev, b->d_status_init, parallel ? b->d_opstate : nullptr, parallel ? b->opstate_bytes / 8 : 0,
                      b->dev.dbg ? (uint32_t)(P.hwaves.size() * 32) : 0u);
     kt.mark("reset");
+    if (parallel || !b->seq_list.empty()) { pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables"); }      // the exact path uses the decode tables too
     if (parallel) {
-        pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables");
         pjd_launch_lane_words(s, b->dev);    kt.mark("lane_words");
         pjd_launch_huff_lanes(s, b->dev);    kt.mark("huff_lanes");
         pjd_launch_lane_dc_scan(s, b->dev);  kt.mark("dc_scan");
@@ -483,7 +485,13 @@ int settle(pjd_batch *b)
             du += (uint64_t)(g.last_mcu - g.first_mcu) * g.dus_per_mcu;
         }
     b->n_fallback = (int)fb.size();
+    b->exact_fallback_ms = 0;
+    b->n_entropy_errors = 0;
+    for (size_t i = 0; i < n; i++)
+        if (!(b->h_status[i] & PJD_STW_NEEDS_EXACT) && (b->h_status[i] & 0xFF) != 0) b->n_entropy_errors++;
     if (!fb.empty()) {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
         int16_t *coef = nullptr; uint32_t *d_list = nullptr; uint64_t *d_base = nullptr; PjdDevIdctWg *d_wgs = nullptr;
         auto cleanup = [&] { hipFree(coef); hipFree(d_list); hipFree(d_base); hipFree(d_wgs); };
         if (hipMalloc((void **)&coef, du * 64 * sizeof(int16_t)) != hipSuccess || hipMalloc((void **)&d_list, fb.size() * sizeof(uint32_t)) != hipSuccess ||
@@ -500,12 +508,17 @@ int settle(pjd_batch *b)
         if (e == hipSuccess) e = hipMemcpyAsync(d_base, fb_base.data(), fb_base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_wgs, fb_wgs.data(), fb_wgs.size() * sizeof(PjdDevIdctWg), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
+            if (ev0) (void)hipEventRecord(ev0, s);
             pjd_launch_huff_sequential(s, dv, d_list, d_base, (uint32_t)fb.size());
             pjd_launch_idct_colour(s, dv, d_wgs, d_base, (uint32_t)fb_wgs.size());
+            if (ev1) (void)hipEventRecord(ev1, s);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(b->h_status, b->dev.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);        // also: the host vectors above are pageable
+        if (e == hipSuccess && ev0 && ev1) (void)hipEventElapsedTime(&b->exact_fallback_ms, ev0, ev1);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
         cleanup();
         if (e != hipSuccess) { ctx->err = std::string("exact-kernel fallback: ") + hipGetErrorString(e); return PJD_E_HIP; }
     }
@@ -655,6 +668,8 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     info->device_bytes = b->device_bytes;
     info->n_sequential = (int32_t)b->seq_list.size();
     info->n_fallback = b->n_fallback;
+    info->exact_fallback_ms = b->exact_fallback_ms;
+    info->n_entropy_errors = b->n_entropy_errors;
     info->sub_bytes = P.sub_bytes;
     info->n_table_sets = (uint32_t)P.tsets.size();
     info->n_huff_waves = P.hwaves.size();

@@ -945,6 +945,129 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
 }
 
 // ---------------------------------------------------------------------------------------------
+// The EXACT decoder with the parallel decoder's tables: one lane per picture, the reference's decode_Huffman_data in its own
+// order (reference src/jpeg_scanner.cpp:707-756) -- its restart rule (:723; or ITU T.81's with PJD_IF_STANDARD_RESTART), its
+// end-of-data behaviour, its error classes and "stop at the first error, keep what was decoded" -- but every symbol is ONE lookup
+// in the two-level table in LDS and the bitstream comes through a register window, instead of the literal bit-serial scan of
+// pjd_k_huffman_seq.hip (which stays for table sets that have no decode table: over-subscribed codes, too many long codes).
+// Still a single dependent chain per picture -- about eight times faster than the literal kernel, not a fast path.
+// Output as there: coefficients in zigzag-SLOT order, absolute DC, PJD_COEF_SENTINEL for an explicit zero at slot 52.
+// ---------------------------------------------------------------------------------------------
+struct SeqWin {            // bit window over the picture's bitstream itself (unaligned big-endian dwords); p = absolute bit position
+    pjd_gptr base;
+    uint32_t hi, lo, nxt, off;
+    int s;
+    __device__ __forceinline__ uint32_t word(uint32_t byte_off) const
+    {
+        return __builtin_bswap32(reinterpret_cast<const __attribute__((address_space(1))) UnalignedU32 *>(base + byte_off)->v);
+    }
+    __device__ __forceinline__ void init(pjd_gptr b)      // at bit 0
+    {
+        base = b; hi = 0; lo = word(0); nxt = word(4); off = 8; s = 0;
+    }
+    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s); }
+    __device__ __forceinline__ void drop(uint32_t n)      // n <= 32
+    {
+        s -= (int)n;
+        if (s < 0) { s += 32; hi = lo; lo = nxt; nxt = word(off); off += 4; }
+    }
+};
+
+__global__ __launch_bounds__(64) void pjd_k_huff_exact_lut(PjdDevBatch B, const uint32_t *__restrict__ image_list, const uint64_t *__restrict__ dense_base)
+{
+    const uint32_t ii = image_list[blockIdx.x];
+    const PjdDevImage &im = B.images[ii];
+    const PjdDevTset &T = B.tsets[im.tset];
+    if (T.lut_bytes == 0) return;                                // no decode table for this set: pjd_k_huff_sequential takes the picture
+    const uint32_t l = threadIdx.x;
+    uint8_t *lds = pjd_huff_lds;
+    {
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(B.luts) + T.lut_off16;
+        uint4 *tdst = reinterpret_cast<uint4 *>(lds);
+        for (uint32_t i = l; i < T.lut_bytes / 16; i += 64) tdst[i] = tsrc[i];
+    }
+    PhaseCtx P;
+    {
+        const uint32_t dus = im.dus_per_mcu, nc = dus - im.n_luma;
+        const uint32_t c1 = nc >= 1 ? 1u : 0u, c2 = nc >= 2 ? 2u : c1;
+        const uint32_t lb = lds_abs(lds);
+        P.lbase = lb;
+        P.tY  = (lb + (uint32_t)im.tbl_slot[0][0] * PJD_L1_BYTES) | (lb + (uint32_t)im.tbl_slot[0][1] * PJD_L1_BYTES) << 16;
+        P.tC1 = (lb + (uint32_t)im.tbl_slot[c1][0] * PJD_L1_BYTES) | (lb + (uint32_t)im.tbl_slot[c1][1] * PJD_L1_BYTES) << 16;
+        P.tC2 = (lb + (uint32_t)im.tbl_slot[c2][0] * PJD_L1_BYTES) | (lb + (uint32_t)im.tbl_slot[c2][1] * PJD_L1_BYTES) << 16;
+        P.nc = nc; P.dus1 = dus - 1;
+        P.xbase = 0;                                             // the phase table is not used here: tables by component below
+    }
+    __syncthreads();
+    if (l != 0) return;
+
+    int16_t *coef = B.coef + dense_base[blockIdx.x] * 64;        // slot 0 of the scratch = the first data unit this picture (or shard) decodes
+    const uint32_t RI = im.restart_interval, Wr = im.ref_mcu_w_real;
+    const bool std_rule = (im.flags & PJD_IF_STANDARD_RESTART) != 0;
+    const uint32_t nbits = im.ecs_len * 8u;
+    SeqWin w;
+    w.init((pjd_gptr)(B.ecs + im.ecs_off));
+    uint32_t p = 0, D = 0;
+    int pred[3] = {0, 0, 0};
+    int status = PJD_ST_OK;
+    for (uint32_t m = im.first_mcu; m < im.last_mcu && !status; m++) {
+        const uint32_t y = (m / im.mcux) * im.vs, x = (m % im.mcux) * im.hs;
+        if (RI != 0 && (std_rule ? (m % RI == 0) : ((y * Wr + x) % RI == 0))) {
+            pred[0] = pred[1] = pred[2] = 0;
+            // BitReader::align() (reference src/headers/jpeg.h:115-121): a no-op once every byte is consumed
+            if ((p >> 3) < im.ecs_len && (p & 7)) { const uint32_t a = 8u - (p & 7); w.drop(a); p += a; }
+        }
+        for (uint32_t k = 0; k < im.dus_per_mcu && !status; k++, D++) {
+            const uint32_t r = P.dus1 - k, comp = P.comp(r), tabs = P.tabs(r);
+            int16_t *unit = coef + (size_t)D * 64;
+            // ---- DC (jpeg_scanner.cpp:469-486)
+            {
+                const uint32_t pk = w.peek();
+                const uint32_t e = lut_lookup(P.lbase, tabs & 0xffffu, pk);
+                const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e);
+                const uint32_t vbits = size >= PJD_LUT_BADSYM ? 0u : size, codelen = used - vbits, left = nbits > p ? nbits - p : 0u;
+                if (size == PJD_LUT_BADSYM || codelen > left) { status = PJD_ST_DC_SYM; break; }
+                if (size == PJD_LUT_BADLEN) { status = PJD_ST_DC_LEN; break; }
+                if (vbits > left - codelen) { status = PJD_ST_DC_BITS; break; }
+                const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size), m1 = 1u << size;
+                const int val = (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
+                w.drop(used); p += used;
+                unit[0] = (int16_t)(val + pred[comp]);
+                pred[comp] = unit[0];
+            }
+            // ---- AC (jpeg_scanner.cpp:488-518)
+            for (uint32_t z = 1; z < 64; z++) {
+                const uint32_t pk = w.peek();
+                const uint32_t e = lut_lookup(P.lbase, tabs >> 16, pk);
+                const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e), adv = PJD_LUT_ADV(e);
+                const uint32_t vbits = size >= PJD_LUT_BADSYM ? 0u : size, codelen = used - vbits, left = nbits > p ? nbits - p : 0u;
+                if (size == PJD_LUT_BADSYM || codelen > left) { status = PJD_ST_AC_SYM; break; }
+                if (e & PJD_LUT_EOB) { w.drop(used); p += used; break; }
+                const uint32_t run = (adv - 1u) & 15u;
+                if (z + run >= 64) { status = PJD_ST_AC_RUN; break; }
+                z += run;
+                if (size == PJD_LUT_BADLEN) { status = PJD_ST_AC_LEN; break; }
+                if (vbits > left - codelen) { status = PJD_ST_AC_BITS; break; }
+                const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size), m1 = 1u << size;
+                const int val = (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
+                w.drop(used); p += used;
+                // size 0 stores a literal 0 (jpeg_scanner.cpp:516-517); it matters only at slot 52, whose natural position (38)
+                // may already hold slot 48's value
+                unit[z] = (size == 0 && z == 52) ? (int16_t)PJD_COEF_SENTINEL : (int16_t)val;
+            }
+        }
+    }
+    // keep the "decoded by the exact kernel" marker so the back end treats slot 0 as absolute
+    B.status[ii] = (B.status[ii] & PJD_STW_NEEDS_EXACT) | status;
+}
+
+void pjd_launch_huff_exact_lut(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n)
+{
+    if (n == 0 || b.max_lut_bytes == 0) return;
+    hipLaunchKernelGGL(pjd_k_huff_exact_lut, dim3(n), dim3(64), (size_t)b.max_lut_bytes + 64, s, b, image_list, dense_base);
+}
+
+// ---------------------------------------------------------------------------------------------
 static size_t huff_lds_bytes(const PjdDevBatch &b)
 {
     static const size_t extra = [] { const char *e = std::getenv("PJD_EXTRA_LDS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();   // occupancy experiments

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void pjd_k_huff_sequential(PjdDevBatch B, const
     if (threadIdx.x != 0) return;
     const uint32_t ii = image_list[blockIdx.x];
     const PjdDevImage &im = B.images[ii];
+    if (B.tsets[im.tset].lut_bytes != 0) return;                // pjd_k_huff_exact_lut (pjd_k_huffman.hip) decodes it with the decode tables
     const PjdDevHuffRaw *tabs = B.raw_tables + (size_t)im.tset * PJD_MAX_TABLES;
     SeqReader r = { B.ecs + im.ecs_off, im.ecs_len * 8u, 0u };
     // slot 0 of the scratch = the first data unit this image (or this shard of it) decodes
@@ -132,5 +133,6 @@ __global__ __launch_bounds__(64) void pjd_k_huff_sequential(PjdDevBatch B, const
 void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n)
 {
     if (n == 0) return;
+    pjd_launch_huff_exact_lut(s, b, image_list, dense_base, n);         // pictures whose table set has decode tables; the rest below
     hipLaunchKernelGGL(pjd_k_huff_sequential, dim3(n), dim3(64), 0, s, b, image_list, dense_base);
 }

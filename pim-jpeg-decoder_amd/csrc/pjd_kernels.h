@@ -57,6 +57,7 @@ void pjd_launch_coefdump_dense(hipStream_t s, const PjdDevBatch &b, uint32_t ima
 // ---- entropy decode (pjd_k_huffman.hip, pjd_k_huffman_seq.hip) ---------------------
 // exact kernel: image_list[k] decodes into the dense scratch from data unit dense_base[k]
 void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);
+void pjd_launch_huff_exact_lut(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);   // the exact decoder, table-driven
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
 void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b);     // bitstream -> per-lane big-endian words, transposed per wave
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b);     // synchronise + stitch + scan + write

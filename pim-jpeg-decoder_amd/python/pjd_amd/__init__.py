@@ -59,7 +59,8 @@ class BatchInfo(C.Structure):
                 ("n_huff_workgroups", C.c_uint64), ("sync_rounds", C.c_uint64), ("sync_lane_passes", C.c_uint64),
                 ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64),
                 ("sub_bytes", C.c_uint32), ("n_table_sets", C.c_uint32), ("n_huff_waves", C.c_uint64),
-                ("n_entries", C.c_uint64), ("flag_waves", C.c_uint64 * 8)]
+                ("n_entries", C.c_uint64), ("exact_fallback_ms", C.c_float), ("n_entropy_errors", C.c_uint32),
+                ("flag_waves", C.c_uint64 * 8)]
 
 
 SPLIT_MAX_DEVICES = 16
@@ -318,7 +319,7 @@ class Batch:
     def info(self):
         bi = BatchInfo()
         self.ctx._check(self.L.pjd_batch_get_info(self._h, C.byref(bi)), "pjd_batch_get_info")
-        return {k: (list(getattr(bi, k)) if k == "flag_waves" else int(getattr(bi, k))) for k, _ in bi._fields_}
+        return {k: (list(getattr(bi, k)) if k == "flag_waves" else (float(getattr(bi, k)) if k == "exact_fallback_ms" else int(getattr(bi, k)))) for k, _ in bi._fields_}
 
     def output_size(self, i):
         return int(self.L.pjd_batch_output_size(self._h, i))
@@ -511,4 +512,4 @@ def plan_info(descs, out_format=OUT_RGB8):
     rc = L.pjd_plan_info(arr, len(descs), out_format, C.byref(bi))
     if rc != 0:
         raise PjdError(f"pjd_plan_info failed ({rc})")
-    return {k: (list(getattr(bi, k)) if k == "flag_waves" else int(getattr(bi, k))) for k, _ in bi._fields_}
+    return {k: (list(getattr(bi, k)) if k == "flag_waves" else (float(getattr(bi, k)) if k == "exact_fallback_ms" else int(getattr(bi, k)))) for k, _ in bi._fields_}
