@@ -687,6 +687,9 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
         const size_t nw = P.hwaves.size();
         std::vector<uint32_t> d(nw * 32);
         if (hipMemcpy(d.data(), b->dev.dbg, d.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && nw) {
+            if (const char *dump = std::getenv("PJD_DEBUG_DUMP")) {          // the raw timeline (32 words per wave) for offline analysis
+                if (FILE *f = std::fopen(dump, "wb")) { std::fwrite(d.data(), 4, d.size(), f); std::fclose(f); }
+            }
             uint32_t t0 = d[0];
             for (size_t k = 0; k < nw; k++) if ((int32_t)(d[k * 32] - t0) < 0) t0 = d[k * 32];
             double sum[6] = {0}; uint32_t mx[6] = {0}; size_t worst = 0; uint32_t worst_end = 0;
