@@ -34,9 +34,10 @@ extern "C" {
 #endif
 
 /* ABI version: bumped whenever a struct in this header changes size or layout (pjd_image_desc gained qt_slot48 and
- * pjd_batch_info grew in version 2; version 3 adds the coefficient download and the exact-path figures of pjd_batch_info).
+ * pjd_batch_info grew in version 2; version 3 added the coefficient download and pjd_split_*; version 4 the progressive scans of
+ * pjd_image_desc and the exact-path figures of pjd_batch_info).
  * A caller built against another version must not pass its structs: check pjd_version() == PJD_VERSION after loading.     */
-#define PJD_VERSION 3
+#define PJD_VERSION 4
 
 /* ---- error codes (library level) ---------------------------------------- */
 #define PJD_OK              0
@@ -76,6 +77,12 @@ extern "C" {
                                        the quantiser (qt_slot48).  NOT reference-comparable: the
                                        reference has no such mode, parity for it is unpinned.   */
 
+#define PJD_F_PROGRESSIVE       8u  /* a progressive (SOF2) frame: `scans` / `n_scans` describe its scans, `ecs` is unused.  The
+                                       reference cannot decode such files -- its scanner stops at the first marker between scans
+                                       (jpeg_scanner.cpp:425-430) and its progressive branches (:521-704) handle one scan only --
+                                       so this mode is NOT reference-comparable, parity for it is unpinned; it exists for
+                                       SURVEY 8(f) N4 and is opt-in (pjd_scan_*_ex with PJD_SCAN_PROGRESSIVE).                */
+
 /* Huffman table as the reference's scanner holds it (jpeg.h:129-134):
  * offsets[k] = number of codes of length <= k (offsets[0] = 0).               */
 typedef struct pjd_huff_table {
@@ -83,6 +90,19 @@ typedef struct pjd_huff_table {
     uint8_t symbols[162];
     uint8_t set;
 } pjd_huff_table;
+
+/* One scan of a progressive frame (ITU T.81 G.1; the fields the reference's progressive branches read from `Header`:
+ * start_of_selection, end_of_selection, successive_approximation_high / _low, jpeg.h:160-163) with the Huffman tables in
+ * force when the scan starts (tables may be redefined between scans) and its own entropy-coded bytes.                     */
+typedef struct pjd_scan_desc {
+    uint8_t  n_comp;                   /* components in this scan, 1..3 (AC scans: 1)                          */
+    uint8_t  comp[3];                  /* their indices 0..2 (frame order)                                     */
+    uint8_t  ss, se, ah, al;           /* spectral selection, successive approximation                         */
+    uint32_t restart_interval;         /* DRI in force for this scan, in MCUs OF THE SCAN; 0 = none            */
+    pjd_huff_table table[3];           /* per scan component: its DC table (ss == 0) or its AC table (ss > 0)   */
+    const uint8_t *ecs;                /* destuffed, RSTn removed                                              */
+    uint64_t ecs_len;
+} pjd_scan_desc;
 
 /* One parsed baseline JPEG -- exactly the fields of the reference `Header`
  * (jpeg.h:146-179) that its hot path consumes, plus the restart-segment
@@ -113,6 +133,9 @@ typedef struct pjd_image_desc {
     uint32_t qt_slot48[4];             /* DQT entry 48 of each table: the reference's map sends it
                                           to natural 38, where entry 52 overwrites it, so `qt`
                                           does not hold it.  Read only with PJD_F_STANDARD_ZIGZAG. */
+    const pjd_scan_desc *scans;        /* PJD_F_PROGRESSIVE only: the frame's scans in file order    */
+    uint32_t n_scans;
+    uint32_t reserved_;
 } pjd_image_desc;
 
 typedef struct pjd_ctx pjd_ctx;

@@ -32,6 +32,13 @@ typedef struct pjd_scanned pjd_scanned;
 int pjd_scan_memory(const uint8_t *data, uint64_t len, const char *name, pjd_scanned **out);
 int pjd_scan_file(const char *path, pjd_scanned **out);
 
+/* The same with options.  PJD_SCAN_PROGRESSIVE: a progressive (SOF2) file is parsed scan by scan instead of being rejected at
+ * its first inter-scan marker as the reference does (jpeg_scanner.cpp:425-430); the descriptor then carries PJD_F_PROGRESSIVE
+ * and the scan list (pjd_scan_desc).  Baseline files are unaffected.  Not reference behaviour: opt-in.                    */
+#define PJD_SCAN_PROGRESSIVE 1u
+int pjd_scan_memory_ex(const uint8_t *data, uint64_t len, const char *name, uint32_t options, pjd_scanned **out);
+int pjd_scan_file_ex(const char *path, uint32_t options, pjd_scanned **out);
+
 /* The descriptor is valid until pjd_scanned_free; desc->ecs / seg_offsets point into it. */
 const pjd_image_desc *pjd_scanned_desc(const pjd_scanned *s);
 const char *pjd_scanned_log(const pjd_scanned *s);      /* what the reference would print   */

@@ -58,7 +58,7 @@ typedef struct pjd_pipe_opts {
     void *sink_user;
     const int32_t *devices;  /* HIP ordinals to spread the batches over; NULL -> { device }    */
     int32_t n_devices;       /* entries in `devices` (at most PJD_PIPE_MAX_DEVICES)            */
-    int32_t reserved_;
+    uint32_t scan_options;   /* PJD_SCAN_* of pjd_host.h handed to the scanner (0 = the reference's accept / reject set) */
 } pjd_pipe_opts;
 
 typedef struct pjd_pipe_stats {

@@ -271,7 +271,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     };
     const size_t o_images = part(P.images, 0), o_tsets = part(P.tsets, 0), o_raw = part(P.tables, 0), o_qtab = part(P.qtab, 0);
     const size_t o_segs = part(P.segs, 0), o_lanes = part(P.subs, 0), o_hwaves = part(P.hwaves, 0), o_hwgs = part(P.hwgs, 0);
-    const size_t o_iwgs = part(P.iwgs, 0), o_iwgs_dense = part(P.iwgs_dense, 0);
+    const size_t o_iwgs = part(P.iwgs, 0), o_iwgs_dense = part(P.iwgs_dense, 0), o_pscans = part(P.pscans, 0);
     const size_t o_seq_list = part(b->seq_list, (size_t)n_images), o_seq_base = part(seq_base, (size_t)n_images), o_st0 = part(st0, (size_t)n_images);
     const size_t o_ecs = in_bytes;
     in_bytes += P.ecs_buf_bytes;
@@ -286,6 +286,13 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
             if (off > pos) std::memset(h_ecs + pos, 0, off - pos);
             if (len) std::memcpy(h_ecs + off, P.host[i].ecs_src, len);
             pos = off + len;
+            if (P.images[i].flags & PJD_IF_PROGRESSIVE)              // its scans follow, each at its own offset
+                for (uint32_t k = 0; k < P.images[i].n_pscan; k++) {
+                    const PjdHostScan &hs = P.host_scans[P.images[i].pscan_base + k];
+                    if (hs.off > pos) std::memset(h_ecs + pos, 0, hs.off - pos);
+                    if (hs.len) std::memcpy(h_ecs + hs.off, hs.src, hs.len);
+                    pos = hs.off + hs.len;
+                }
         }
         std::memset(h_ecs + pos, 0, P.ecs_buf_bytes - pos);
     }
@@ -310,6 +317,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     b->d_segs = (PjdDevSegment *)(b->d_in + o_segs); b->d_lanes = (PjdDevSub *)(b->d_in + o_lanes);
     b->d_hwaves = (PjdDevHuffWave *)(b->d_in + o_hwaves); b->d_hwgs = (PjdDevHuffWg *)(b->d_in + o_hwgs);
     b->d_iwgs = (PjdDevIdctWg *)(b->d_in + o_iwgs); b->d_iwgs_dense = (PjdDevIdctWg *)(b->d_in + o_iwgs_dense);
+    b->dev.pscans = (const PjdDevScan *)(b->d_in + o_pscans);
     b->d_seq_list = (uint32_t *)(b->d_in + o_seq_list); b->d_seq_base = (uint64_t *)(b->d_in + o_seq_base);
     b->d_status_init = (int32_t *)(b->d_in + o_st0);
     b->d_ecs = b->d_in + o_ecs;
@@ -431,6 +439,7 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings)
         // images routed to the exact kernel: dense int16 scratch, cleared first (unvisited slots are zero)
         pjd_launch_zero(s, b->dev.coef, P.dense_du * 64 * sizeof(int16_t));      // a kernel, not a memset node: see the reset above
         pjd_launch_huff_sequential(s, b->dev, b->d_seq_list, b->d_seq_base, (uint32_t)b->seq_list.size());
+        if (!P.pscans.empty()) pjd_launch_progressive(s, b->dev, b->d_seq_list, b->d_seq_base, (uint32_t)b->seq_list.size());
         pjd_launch_idct_colour(s, b->dev, b->d_iwgs_dense, b->d_seq_base, (uint32_t)P.iwgs_dense.size());
         kt.mark("exact_path");
     }

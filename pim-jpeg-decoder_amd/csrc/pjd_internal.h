@@ -78,6 +78,7 @@
 #define PJD_IF_SEQUENTIAL       2u  // routed to the exact one-lane kernel up front
 #define PJD_IF_BMP              4u  // output is a BMP file image (else tight RGB8)
 #define PJD_IF_STANDARD_ZIGZAG  8u  // zigzag slot 48 -> natural 58, no slot-52 override (PJD_F_STANDARD_ZIGZAG)
+#define PJD_IF_PROGRESSIVE      32u // a progressive frame: decoded scan by scan into the dense scratch by pjd_k_progressive (PJD_F_PROGRESSIVE)
 #define PJD_IF_ENDS_STREAM      16u // the last restart segment this image (or shard) decodes is the last of its bitstream: running out of
                                     // bits there is the reference's end-of-data error, handled by the parallel decoder itself
 
@@ -139,6 +140,7 @@ struct PjdDevImage {
     uint32_t sub_bytes;                // subsequence size of THIS image (<= the batch's, which sizes word rows and lane regions)
     uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1 of the set
     uint8_t  pad_[2];
+    uint32_t pscan_base, n_pscan;      // progressive frames: their scans in PjdDevBatch::pscans
 };
 
 // raw Huffman table as shipped by the host (reference HuffmanTable, jpeg.h:129-134)
@@ -147,6 +149,16 @@ struct PjdDevHuffRaw {
     uint8_t symbols[162];
     uint8_t is_ac;
 };                                     // 180 bytes
+
+// One scan of a progressive frame (pjd_scan_desc): what it refines, with which tables, and where its bytes lie
+struct PjdDevScan {
+    uint64_t ecs_off;                  // into the batch bitstream buffer
+    uint32_t ecs_len;
+    uint32_t restart_interval;         // in MCUs of THIS scan
+    uint8_t  n_comp, comp[3];
+    uint8_t  ss, se, ah, al;
+    PjdDevHuffRaw table[3];            // per scan component: DC table (ss == 0) or AC table
+};
 
 // One table set = the deduplicated Huffman tables of an image; images with identical sets share one (a batch of
 // files written with the Annex-K tables has a single set), and so can the waves of one Huffman workgroup.

@@ -977,6 +977,7 @@ __global__ __launch_bounds__(64) void pjd_k_huff_exact_lut(PjdDevBatch B, const 
 {
     const uint32_t ii = image_list[blockIdx.x];
     const PjdDevImage &im = B.images[ii];
+    if (im.flags & PJD_IF_PROGRESSIVE) return;                    // pjd_k_progressive decodes it
     const PjdDevTset &T = B.tsets[im.tset];
     if (T.lut_bytes == 0) return;                                // no decode table for this set: pjd_k_huff_sequential takes the picture
     const uint32_t l = threadIdx.x;

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void pjd_k_huff_sequential(PjdDevBatch B, const
     if (threadIdx.x != 0) return;
     const uint32_t ii = image_list[blockIdx.x];
     const PjdDevImage &im = B.images[ii];
+    if (im.flags & PJD_IF_PROGRESSIVE) return;                   // pjd_k_progressive decodes it
     if (B.tsets[im.tset].lut_bytes != 0) return;                // pjd_k_huff_exact_lut (pjd_k_huffman.hip) decodes it with the decode tables
     const PjdDevHuffRaw *tabs = B.raw_tables + (size_t)im.tset * PJD_MAX_TABLES;
     SeqReader r = { B.ecs + im.ecs_off, im.ecs_len * 8u, 0u };

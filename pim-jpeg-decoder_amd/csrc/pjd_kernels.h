@@ -17,6 +17,7 @@ struct PjdDevBatch {
     const PjdDevHuffWave *hwaves;
     const PjdDevHuffWg *hwgs;
     const PjdDevIdctWg *iwgs;
+    const PjdDevScan *pscans;            // scans of the progressive frames of the batch (PjdDevImage::pscan_base)
     const uint8_t *ecs;
     uint32_t *words;                     // transposed bitstream words: [wave][PJD_WORD_ROWS][64]
     int16_t *coef;                       // DENSE scratch (exact-kernel path): dense_du * 64 int16, zigzag-slot order
@@ -58,6 +59,8 @@ void pjd_launch_coefdump_dense(hipStream_t s, const PjdDevBatch &b, uint32_t ima
 // exact kernel: image_list[k] decodes into the dense scratch from data unit dense_base[k]
 void pjd_launch_huff_sequential(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);
 void pjd_launch_huff_exact_lut(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);   // the exact decoder, table-driven
+// progressive frames among image_list (the others are skipped): scan by scan into the dense scratch (pjd_k_progressive.hip)
+void pjd_launch_progressive(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
 void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b);     // bitstream -> per-lane big-endian words, transposed per wave
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b);     // synchronise + stitch + scan + write

@@ -94,12 +94,35 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         if (d.num_components < 1 || d.num_components > 3) { err = fmt("image %d: num_components must be 1..3", i); return PJD_E_ARG; }
         if ((d.h_samp != 1 && d.h_samp != 2) || (d.v_samp != 1 && d.v_samp != 2)) { err = fmt("image %d: luma sampling must be 1 or 2", i); return PJD_E_ARG; }
         if (d.comp_h[0] != d.h_samp || d.comp_v[0] != d.v_samp) { err = fmt("image %d: comp_h/v[0] must equal h_samp/v_samp", i); return PJD_E_ARG; }
+        const bool progressive = (d.flags & PJD_F_PROGRESSIVE) != 0;
         for (int c = 0; c < d.num_components; c++) {
             if (c > 0 && (d.comp_h[c] != 1 || d.comp_v[c] != 1)) { err = fmt("image %d: chroma sampling must be 1x1", i); return PJD_E_ARG; }
             if (d.comp_qt[c] > 3 || d.comp_dc[c] > 3 || d.comp_ac[c] > 3) { err = fmt("image %d: table selector > 3", i); return PJD_E_ARG; }
-            if (!d.qt_set[d.comp_qt[c]] || !d.dc[d.comp_dc[c]].set || !d.ac[d.comp_ac[c]].set) { err = fmt("image %d: component uses an unset table", i); return PJD_E_ARG; }
+            if (!d.qt_set[d.comp_qt[c]]) { err = fmt("image %d: component uses an unset table", i); return PJD_E_ARG; }
+            if (!progressive && (!d.dc[d.comp_dc[c]].set || !d.ac[d.comp_ac[c]].set)) { err = fmt("image %d: component uses an unset table", i); return PJD_E_ARG; }
         }
-        for (int c = 0; c < d.num_components; c++)
+        if (progressive) {
+            // the scans carry their own tables (pjd_scan_desc); what a scan may be is ITU T.81 G.1.1.1 (the reference checks the same
+            // in its SOS reader, src/jpeg_scanner.cpp:88-112)
+            if (!d.scans || d.n_scans == 0 || d.n_scans > 4096) { err = fmt("image %d: progressive frame without scans", i); return PJD_E_ARG; }
+            if (d.shard_n_segs != 0) { err = fmt("image %d: a progressive frame cannot be sharded", i); return PJD_E_ARG; }
+            for (uint32_t k = 0; k < d.n_scans; k++) {
+                const pjd_scan_desc &sc = d.scans[k];
+                bool ok = sc.n_comp >= 1 && sc.n_comp <= 3 && sc.n_comp <= d.num_components && sc.ss <= sc.se && sc.se <= 63 && sc.al <= 13 && sc.ah <= 13;
+                ok = ok && !(sc.ss == 0 && sc.se != 0) && !(sc.ss != 0 && sc.n_comp != 1) && (sc.ah == 0 || sc.al + 1 == sc.ah);
+                for (int q = 0; ok && q < sc.n_comp; q++) {
+                    ok = sc.comp[q] < d.num_components && (q == 0 || sc.comp[q] > sc.comp[q - 1]);
+                    const pjd_huff_table &t = sc.table[q];
+                    const bool needs_table = !(sc.ss == 0 && sc.ah != 0);          // a DC refinement scan reads raw bits
+                    if (needs_table) {
+                        ok = ok && t.set && t.offsets[0] == 0 && t.offsets[16] <= 162;
+                        for (int l = 1; ok && l <= 16; l++) ok = t.offsets[l] >= t.offsets[l - 1];
+                    }
+                }
+                if (!ok || (sc.ecs_len > 0 && !sc.ecs) || sc.ecs_len >= (1ull << 29)) { err = fmt("image %d: malformed scan %ld", i, (long)k); return PJD_E_ARG; }
+            }
+        }
+        for (int c = 0; c < d.num_components && !progressive; c++)
             for (int a = 0; a < 2; a++) {
                 const pjd_huff_table &t = a ? d.ac[d.comp_ac[c]] : d.dc[d.comp_dc[c]];
                 bool ok = t.offsets[0] == 0 && t.offsets[16] <= 162;
@@ -141,7 +164,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         int nt = 0;
         const pjd_huff_table *seen[PJD_MAX_TABLES];
         uint8_t seen_ac[PJD_MAX_TABLES];
-        for (int c = 0; c < (int)g.ncomp; c++)
+        for (int c = 0; c < (int)g.ncomp && !progressive; c++)
             for (int a = 0; a < 2; a++) {
                 const pjd_huff_table *t = a ? &d.ac[d.comp_ac[c]] : &d.dc[d.comp_dc[c]];
                 int sl = -1;
@@ -158,7 +181,8 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             key.append(reinterpret_cast<const char *>(seen[k]->symbols), 162);
         }
         auto found = tset_of.find(key);
-        if (found == tset_of.end()) {
+        if (progressive) found = tset_of.end();                 // no table set: the scans bring their tables
+        else if (found == tset_of.end()) {
             const uint32_t ts = (uint32_t)P.tsets.size();
             found = tset_of.emplace(std::move(key), ts).first;
             PjdDevTset T;
@@ -203,14 +227,15 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             P.tsets.push_back(T);
             tset_parallel.push_back(ok ? 1 : 0);
         }
-        g.tset = found->second;
-        const bool tables_parallel_ok = tset_parallel[g.tset] != 0;
+        g.tset = progressive ? 0u : found->second;
+        const bool tables_parallel_ok = !progressive && tset_parallel[g.tset] != 0;
 
         // ---- restart segments and routing
         const uint32_t RI = d.restart_interval;
         const bool luma11 = (g.hs == 1 && g.vs == 1);
         const bool std_rule = (d.flags & PJD_F_STANDARD_RESTART) != 0;
         bool sequential = (d.flags & PJD_F_FORCE_SEQUENTIAL) != 0 || !tables_parallel_ok;
+        if (progressive) g.flags |= PJD_IF_PROGRESSIVE;
         if (g.n_du + 1 >= (1u << 28)) sequential = true;  // look-back descriptors carry 28-bit unit indices, saturating at n_du + 1
         uint32_t nseg_total = 1;
         if (RI != 0) {
@@ -242,11 +267,32 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         g.first_mcu = (RI != 0 && !sequential) ? seg_lo * RI : 0;
         g.last_mcu = (RI != 0 && !sequential && seg_hi < nseg_total) ? seg_hi * RI : g.n_mcu;
 
-        h.ecs_src = d.ecs ? d.ecs + byte_lo : nullptr;
-        h.ecs_copy_len = byte_hi - byte_lo;
+        h.ecs_src = (d.ecs && !progressive) ? d.ecs + byte_lo : nullptr;
+        h.ecs_copy_len = progressive ? 0 : byte_hi - byte_lo;
         g.ecs_len = (uint32_t)h.ecs_copy_len;
         g.ecs_off = ecs_off;
         ecs_off = align_up(ecs_off + h.ecs_copy_len + 48, 16);   // >= 48 zero bytes after every stream (a symbol may start on its last bit)
+        if (progressive) {
+            g.pscan_base = (uint32_t)P.pscans.size();
+            g.n_pscan = d.n_scans;
+            for (uint32_t k = 0; k < d.n_scans; k++) {
+                const pjd_scan_desc &sc = d.scans[k];
+                PjdDevScan ds;
+                std::memset(&ds, 0, sizeof ds);
+                ds.ecs_off = ecs_off; ds.ecs_len = (uint32_t)sc.ecs_len; ds.restart_interval = sc.restart_interval;
+                ds.n_comp = sc.n_comp; ds.ss = sc.ss; ds.se = sc.se; ds.ah = sc.ah; ds.al = sc.al;
+                for (int q = 0; q < sc.n_comp; q++) {
+                    ds.comp[q] = sc.comp[q];
+                    std::memcpy(ds.table[q].offsets, sc.table[q].offsets, 17);
+                    std::memcpy(ds.table[q].symbols, sc.table[q].symbols, 162);
+                    ds.table[q].is_ac = sc.ss != 0;
+                }
+                P.pscans.push_back(ds);
+                P.host_scans.push_back({sc.ecs, sc.ecs_len, ecs_off});
+                ecs_off = align_up(ecs_off + sc.ecs_len + 48, 16);
+                P.ecs_bytes += sc.ecs_len;
+            }
+        }
 
         g.seg_base = (uint32_t)P.segs.size();
         g.lane_base = (uint32_t)P.subs.size();

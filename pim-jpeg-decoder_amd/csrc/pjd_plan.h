@@ -10,7 +10,12 @@ struct PjdHostImage {
     const uint8_t *ecs_src;     // caller memory: first byte to upload
     uint64_t ecs_copy_len;      // bytes to upload
     uint64_t out_bytes;         // size of this picture in the chosen output format
-    bool sequential;            // routed to the exact one-lane kernel up front
+    bool sequential;            // routed to the exact one-lane kernel up front (or a progressive frame: pjd_k_progressive)
+};
+
+struct PjdHostScan {            // bytes of one scan of a progressive frame: where they come from, where they go
+    const uint8_t *src;
+    uint64_t len, off;
 };
 
 struct PjdPlan {
@@ -29,7 +34,9 @@ struct PjdPlan {
     std::vector<PjdDevHuffWg> hwgs;        // up to 4 consecutive waves of one table set
     std::vector<PjdDevIdctWg> iwgs;        // images decoded by the parallel path (lane-stream back end)
     std::vector<PjdDevIdctWg> iwgs_dense;  // images routed to the exact kernel up front (dense back end)
-    std::vector<uint32_t> seq_images;      // indices of `sequential` images
+    std::vector<PjdDevScan> pscans;        // scans of progressive frames
+    std::vector<PjdHostScan> host_scans;   // one per entry of pscans
+    std::vector<uint32_t> seq_images;      // indices of `sequential` images (progressive frames included)
     std::vector<uint32_t> fast_images;     // the others
     uint64_t ecs_buf_bytes = 0;            // size of the packed bitstream buffer (incl. padding)
     uint64_t n_du = 0;                     // data units in the batch

@@ -18,6 +18,8 @@
 // as the reference spreads pictures over all allocated DPUs (:225); it implies --pipeline.
 // --split [--devices 0,1,...]: every picture is decoded by all listed devices TOGETHER (pjd_split_decode): restart-segment ranges per
 // device, the descriptor broadcast with RCCL, rows assembled on the host -- for single pictures larger than one device's share.
+// --progressive: progressive (SOF2) files are decoded scan by scan instead of being rejected as the reference rejects them
+// (not reference behaviour, parity unpinned).
 #include <sys/stat.h>
 #include <time.h>
 
@@ -65,7 +67,7 @@ static void pipe_sink(void *user, int index, const char *name, const char *log, 
 }
 
 static int run_pipeline(const std::vector<std::string> &files, const std::vector<int32_t> &devices, int batch_images, int slots, int scan_threads,
-                        int write_threads)
+                        int write_threads, uint32_t scan_options)
 {
     std::vector<const char *> paths;
     for (const std::string &f : files) paths.push_back(f.c_str());
@@ -77,6 +79,7 @@ static int run_pipeline(const std::vector<std::string> &files, const std::vector
     o.out_format = PJD_OUT_BMP; o.batch_images = batch_images;
     o.slots = slots; o.scan_threads = scan_threads; o.sink_threads = write_threads;
     o.sink = pipe_sink; o.sink_user = &po;
+    o.scan_options = scan_options;
     pjd_pipe_stats st;
     const int rc = pjd_pipe_run_files(paths.data(), (int)paths.size(), &o, &st);
     if (rc == PJD_E_NODEVICE) {
@@ -109,7 +112,7 @@ static int run_pipeline(const std::vector<std::string> &files, const std::vector
 // For pictures larger than one device's share: the reference spreads every picture over all its DPUs (decoder_host.cpp:125-149,
 // 225); here a picture with restart intervals is cut into restart-segment ranges, one per device, the descriptor is broadcast
 // with RCCL and the rows are assembled on the host.  Pictures that cannot be cut are decoded by the first device.
-static int run_split(const std::vector<std::string> &files, const std::vector<int32_t> &devices)
+static int run_split(const std::vector<std::string> &files, const std::vector<int32_t> &devices, uint32_t scan_options)
 {
     double t_total = now_s(), t_scan = 0, t_bc = 0, t_up = 0, t_exec = 0, t_down = 0, t_bmp = 0;
     int calls = 0, rccl_calls = 0;
@@ -117,7 +120,7 @@ static int run_split(const std::vector<std::string> &files, const std::vector<in
     for (const std::string &f : files) {
         double t0 = now_s();
         pjd_scanned *s = nullptr;
-        const int sr = pjd_scan_file(f.c_str(), &s);
+        const int sr = pjd_scan_file_ex(f.c_str(), scan_options, &s);
         t_scan += now_s() - t0;
         if (sr == 2) { std::cout << f << ": Error - Error opening input file\n" << f << ": Error - Invalid JPEG\n"; continue; }
         std::cout << pjd_scanned_log(s);
@@ -162,6 +165,7 @@ int main(int argc, char **argv)
     int device = 0;
     size_t batch_images = 1024;
     bool pipeline = false, split = false;
+    uint32_t scan_options = 0;
     int slots = 0, scan_threads = 0, write_threads = 0;
     std::vector<std::string> files;
     std::vector<int32_t> devices;
@@ -180,6 +184,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch_images = (size_t)std::atoll(argv[++i]);
         else if (!std::strcmp(argv[i], "--pipeline")) pipeline = true;
         else if (!std::strcmp(argv[i], "--split")) split = true;
+        else if (!std::strcmp(argv[i], "--progressive")) scan_options |= PJD_SCAN_PROGRESSIVE;
         else if (!std::strcmp(argv[i], "--slots") && i + 1 < argc) slots = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--scan-threads") && i + 1 < argc) scan_threads = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--write-threads") && i + 1 < argc) write_threads = std::atoi(argv[++i]);
@@ -201,13 +206,13 @@ int main(int argc, char **argv)
         for (const auto &p : sized) ordered.push_back(p.second);
         if (devices.empty()) devices.push_back(device);
         for (int32_t d : devices) if (d < 0) { std::cout << "Error - Invalid arguments\n"; return 1; }
-        return run_split(ordered, devices);
+        return run_split(ordered, devices, scan_options);
     }
     if (pipeline) {
         std::vector<std::string> ordered;
         for (const auto &p : sized) ordered.push_back(p.second);
         if (devices.empty()) devices.push_back(device);
-        return run_pipeline(ordered, devices, (int)batch_images, slots, scan_threads, write_threads);
+        return run_pipeline(ordered, devices, (int)batch_images, slots, scan_threads, write_threads, scan_options);
     }
 
     pjd_ctx *ctx = nullptr;
@@ -232,7 +237,7 @@ int main(int argc, char **argv)
         while (next < sized.size() && scanned.size() < batch_images) {
             const std::string &f = sized[next++].second;
             pjd_scanned *s = nullptr;
-            int sr = pjd_scan_file(f.c_str(), &s);
+            int sr = pjd_scan_file_ex(f.c_str(), scan_options, &s);
             if (sr == 2) {
                 std::cout << f << ": Error - Error opening input file\n" << f << ": Error - Invalid JPEG\n";
                 continue;

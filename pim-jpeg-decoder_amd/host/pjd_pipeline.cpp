@@ -167,10 +167,10 @@ struct Pipe {
             if (x.path) {
                 struct stat sb;
                 if (stat(x.path, &sb) == 0) in_bytes += (uint64_t)sb.st_size;
-                x.scan_rc = pjd_scan_file(x.path, &x.sc);
+                x.scan_rc = pjd_scan_file_ex(x.path, o.scan_options, &x.sc);
             } else {
                 in_bytes += x.len;
-                x.scan_rc = pjd_scan_memory(x.data, x.len, x.name, &x.sc);
+                x.scan_rc = pjd_scan_memory_ex(x.data, x.len, x.name, o.scan_options, &x.sc);
             }
             t_scan += now_s() - t0;
             Job &j = *jobs[i / o.batch_images];

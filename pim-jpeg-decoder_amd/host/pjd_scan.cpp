@@ -54,6 +54,11 @@ struct pjd_scanned {
     uint8_t frame_type = 0;
     bool zero_based = false, in_frame[3] = {false, false, false}, in_scan[3] = {false, false, false};
     uint32_t mcu_w = 0, mcu_h = 0, mcu_w_real = 0, mcu_h_real = 0;
+    // PJD_SCAN_PROGRESSIVE: the scans of a progressive frame (descriptors + their destuffed bytes)
+    uint32_t options = 0;
+    uint8_t last_ss = 0, last_se = 63, last_ah = 0, last_al = 0, last_ncs = 0, last_comp[3] = {0, 0, 0};
+    std::vector<pjd_scan_desc> scans;
+    std::vector<std::vector<uint8_t>> scan_ecs;
 
     void say(const char *fmt, ...)
     {
@@ -191,6 +196,9 @@ void scan_header(Bytes &in, pjd_scanned &s)
     const unsigned ss = (uint8_t)in.get(), se = (uint8_t)in.get();
     const uint8_t sa = (uint8_t)in.get();
     const unsigned ah = sa >> 4, al = sa & 15;
+    s.last_ss = (uint8_t)ss; s.last_se = (uint8_t)se; s.last_ah = (uint8_t)ah; s.last_al = (uint8_t)al;
+    s.last_ncs = 0;
+    for (unsigned c = 0; c < d.num_components && s.last_ncs < 3; c++) if (s.in_scan[c]) s.last_comp[s.last_ncs++] = (uint8_t)c;
     if (s.frame_type == 0xC0) {
         if (ss != 0 || se != 63) return s.reject(": Error - Invalid spectral selection\n");
         if (ah != 0 || al != 0) return s.reject(": Error - Invalid successive approximation\n");
@@ -281,6 +289,78 @@ bool entropy_segment(Bytes &in, pjd_scanned &s)
     }
 }
 
+// Entropy-coded data of ONE scan of a progressive frame: like entropy_segment, but the scan ends at the next marker that is
+// neither a restart marker nor stuffing; that marker is left to the caller (in.pos on its 0xFF).
+bool scan_bytes(Bytes &in, pjd_scanned &s, std::vector<uint8_t> &out)
+{
+    const uint8_t *p = in.p;
+    const uint64_t n = in.n;
+    uint64_t i = in.pos;
+    out.clear();
+    for (;;) {
+        const uint8_t *ff = i < n ? (const uint8_t *)std::memchr(p + i, 0xFF, n - i) : nullptr;
+        if (!ff) { s.reject(": Error - File ended prematurely\n"); return false; }
+        const uint64_t k = (uint64_t)(ff - p);
+        out.insert(out.end(), p + i, p + k);
+        uint64_t j = k + 1;
+        while (j < n && p[j] == 0xFF) j++;
+        if (j >= n) { s.reject(": Error - File ended prematurely\n"); return false; }
+        const uint8_t m = p[j];
+        if (m == 0x00) { out.push_back(0xFF); i = j + 1; continue; }
+        if (m >= 0xD0 && m <= 0xD7) { i = j + 1; continue; }
+        in.pos = j - 1;                                       // the marker's 0xFF
+        return true;
+    }
+}
+
+// PJD_SCAN_PROGRESSIVE: the scans of a progressive frame, first SOS header already parsed (ITU T.81 B.2.3; what the reference's
+// single-scan progressive branches would need for every scan, src/jpeg_scanner.cpp:521-704).  Tables and restart intervals may
+// be redefined between scans: every scan descriptor carries the tables in force when it starts.
+void progressive_scans(Bytes &in, pjd_scanned &s)
+{
+    pjd_image_desc &d = s.d;
+    for (;;) {
+        pjd_scan_desc sc;
+        std::memset(&sc, 0, sizeof sc);
+        sc.n_comp = s.last_ncs;
+        for (unsigned k = 0; k < sc.n_comp; k++) {
+            const unsigned c = s.last_comp[k];
+            sc.comp[k] = (uint8_t)c;
+            sc.table[k] = s.last_ss == 0 ? d.dc[d.comp_dc[c]] : d.ac[d.comp_ac[c]];
+        }
+        sc.ss = s.last_ss; sc.se = s.last_se; sc.ah = s.last_ah; sc.al = s.last_al;
+        sc.restart_interval = d.restart_interval;
+        if (sc.al > 13) return s.reject(": Error - Invalid successive approximation\n");
+        s.scan_ecs.emplace_back();
+        if (!scan_bytes(in, s, s.scan_ecs.back())) return;
+        s.scans.push_back(sc);
+        // markers up to the next SOS or EOI
+        for (;;) {
+            const int a = in.get(), b = in.get();
+            if (in.bad || a != 0xFF) return s.reject(": Error - Expected a marker\n");
+            uint8_t cur = (uint8_t)b;
+            while (cur == 0xFF) cur = (uint8_t)in.get();
+            if (cur == 0xD9) goto done;
+            if (cur == 0xC4) huffman_tables(in, s);
+            else if (cur == 0xDB) quant_tables(in, s);
+            else if (cur == 0xDD) { const uint32_t l = in.be16(); d.restart_interval = in.be16(); if (l - 4 != 0) s.reject(": Error - DRI invalid\n"); }
+            else if (cur == 0xDA) { scan_header(in, s); break; }
+            else if ((cur >= 0xE0 && cur <= 0xEF) || cur == 0xFE) skip_segment(in);
+            else return s.reject(": Error - Invalid marker during compressed data scan: 0x%x\n", (unsigned)cur);
+            if (!s.valid || in.bad) { if (s.valid) s.reject(": Error - File ended prematurely\n"); return; }
+        }
+        if (!s.valid) return;
+        if (s.scans.size() > 1024) return s.reject(": Error - Too many scans\n");
+    }
+done:
+    for (size_t k = 0; k < s.scans.size(); k++) { s.scans[k].ecs = s.scan_ecs[k].data(); s.scans[k].ecs_len = s.scan_ecs[k].size(); }
+    d.scans = s.scans.data();
+    d.n_scans = (uint32_t)s.scans.size();
+    d.flags |= PJD_F_PROGRESSIVE;
+    d.ecs = nullptr; d.ecs_len = 0; d.seg_offsets = nullptr; d.n_segments = 0;
+    d.restart_interval = 0;                                   // per scan (pjd_scan_desc)
+}
+
 void scan_all(const uint8_t *data, uint64_t len, pjd_scanned &s)
 {
     Bytes in{data, len};
@@ -319,6 +399,7 @@ void scan_all(const uint8_t *data, uint64_t len, pjd_scanned &s)
     // The reference reads one byte ahead before its loop and tests the stream at the top of
     // every iteration; an SOS header that ends exactly at end-of-file is "ended prematurely".
     if (in.bad) { s.reject(": Error - File ended prematurely\n"); return; }
+    if (s.frame_type == 0xC2 && (s.options & PJD_SCAN_PROGRESSIVE)) { progressive_scans(in, s); return; }
     if (!entropy_segment(in, s)) return;
     if (s.frame_type == 0xC2) {
         // A progressive frame whose first scan runs to EOI would enter the reference's
@@ -338,15 +419,23 @@ extern "C" {
 
 int pjd_scan_memory(const uint8_t *data, uint64_t len, const char *name, pjd_scanned **out)
 {
+    return pjd_scan_memory_ex(data, len, name, 0, out);
+}
+
+int pjd_scan_file(const char *path, pjd_scanned **out) { return pjd_scan_file_ex(path, 0, out); }
+
+int pjd_scan_memory_ex(const uint8_t *data, uint64_t len, const char *name, uint32_t options, pjd_scanned **out)
+{
     pjd_scanned *s = new pjd_scanned;
     s->name = name ? name : "";
+    s->options = options;
     scan_all(data, len, *s);
     if (!s->valid) s->say(": Error - Invalid JPEG\n");
     *out = s;
     return s->valid ? 0 : 1;
 }
 
-int pjd_scan_file(const char *path, pjd_scanned **out)
+int pjd_scan_file_ex(const char *path, uint32_t options, pjd_scanned **out)
 {
     *out = nullptr;
     FILE *f = std::fopen(path, "rb");
@@ -357,7 +446,7 @@ int pjd_scan_file(const char *path, pjd_scanned **out)
     std::fseek(f, 0, SEEK_SET);
     if (sz > 0) { buf.resize((size_t)sz); if (std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) buf.clear(); }
     std::fclose(f);
-    return pjd_scan_memory(buf.data(), buf.size(), path, out);
+    return pjd_scan_memory_ex(buf.data(), buf.size(), path, options, out);
 }
 
 const pjd_image_desc *pjd_scanned_desc(const pjd_scanned *s) { return &s->d; }

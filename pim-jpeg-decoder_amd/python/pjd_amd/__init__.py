@@ -16,13 +16,19 @@ LIBHOST = os.path.join(LIB_DIR, "libpjdhost.so")
 LIBPIPE = os.path.join(LIB_DIR, "libpjdpipe.so")
 
 OUT_RGB8, OUT_BMP = 0, 1
-F_STANDARD_RESTART, F_FORCE_SEQUENTIAL, F_STANDARD_ZIGZAG = 1, 2, 4
+F_STANDARD_RESTART, F_FORCE_SEQUENTIAL, F_STANDARD_ZIGZAG, F_PROGRESSIVE = 1, 2, 4, 8
+SCAN_PROGRESSIVE = 1
 MAX_KERNELS = 16
-ABI_VERSION = 3          # PJD_VERSION of include/pjd.h these ctypes structs mirror
+ABI_VERSION = 4          # PJD_VERSION of include/pjd.h these ctypes structs mirror
 
 
 class HuffTable(C.Structure):
     _fields_ = [("offsets", C.c_uint8 * 17), ("symbols", C.c_uint8 * 162), ("set", C.c_uint8)]
+
+
+class ScanDesc(C.Structure):
+    _fields_ = [("n_comp", C.c_uint8), ("comp", C.c_uint8 * 3), ("ss", C.c_uint8), ("se", C.c_uint8), ("ah", C.c_uint8), ("al", C.c_uint8),
+                ("restart_interval", C.c_uint32), ("table", HuffTable * 3), ("ecs", C.c_void_p), ("ecs_len", C.c_uint64)]
 
 
 class ImageDesc(C.Structure):
@@ -40,6 +46,7 @@ class ImageDesc(C.Structure):
         ("flags", C.c_uint32),
         ("shard_first_seg", C.c_uint32), ("shard_n_segs", C.c_uint32),
         ("qt_slot48", C.c_uint32 * 4),
+        ("scans", C.POINTER(ScanDesc)), ("n_scans", C.c_uint32), ("reserved_", C.c_uint32),
     ]
 
 
@@ -94,6 +101,10 @@ def host_lib():
         L.pjd_scan_memory.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.POINTER(C.c_void_p)]
         L.pjd_scan_file.restype = C.c_int
         L.pjd_scan_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.pjd_scan_memory_ex.restype = C.c_int
+        L.pjd_scan_memory_ex.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.pjd_scan_file_ex.restype = C.c_int
+        L.pjd_scan_file_ex.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.pjd_scanned_desc.restype = C.POINTER(ImageDesc)
         L.pjd_scanned_desc.argtypes = [C.c_void_p]
         L.pjd_scanned_log.restype = C.c_char_p
@@ -181,16 +192,17 @@ def dev_lib():
 class Scanned:
     """A parsed JPEG (host side).  Mirrors the reference's `Header` for the decode path."""
 
-    def __init__(self, data: bytes = None, name: str = "x.jpg", path: str = None):
+    def __init__(self, data: bytes = None, name: str = "x.jpg", path: str = None, options: int = 0):
+        """options: SCAN_PROGRESSIVE parses a progressive file scan by scan (not reference behaviour: the reference rejects it)."""
         L = host_lib()
         h = C.c_void_p()
         if path is not None:
-            rc = L.pjd_scan_file(path.encode(), C.byref(h))
+            rc = L.pjd_scan_file_ex(path.encode(), options, C.byref(h))
             if rc == 2:
                 raise FileNotFoundError(path)
         else:
             self._data = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
-            rc = L.pjd_scan_memory(self._data.ctypes.data, len(data), name.encode(), C.byref(h))
+            rc = L.pjd_scan_memory_ex(self._data.ctypes.data, len(data), name.encode(), options, C.byref(h))
         self._h = h
         self.rc = rc
         self.valid = bool(L.pjd_scanned_valid(h))
@@ -373,7 +385,7 @@ class PipeOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("out_format", C.c_int32), ("batch_images", C.c_int32),
                 ("scan_threads", C.c_int32), ("slots", C.c_int32), ("sink_threads", C.c_int32),
                 ("sink", SINK_FN), ("sink_user", C.c_void_p),
-                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_int32), ("reserved_", C.c_int32)]
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_int32), ("scan_options", C.c_uint32)]
 
 
 PIPE_MAX_DEVICES = 16
@@ -433,7 +445,7 @@ def pipe_assign(costs, n_devices):
 
 
 def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_images=1024, scan_threads=0, slots=0,
-             sink_threads=0, sink=None, device=0, devices=None):
+             sink_threads=0, sink=None, device=0, devices=None, scan_options=0):
     """Run the pipelined batcher over in-memory JPEGs (`jpegs`: list of bytes) or files (`paths`).
     `devices`: HIP ordinals to spread the batches over (default: `device` alone).
 
@@ -443,6 +455,7 @@ def pipe_run(jpegs=None, names=None, paths=None, out_format=OUT_BMP, batch_image
     o = PipeOpts()
     o.device, o.out_format, o.batch_images = device, out_format, batch_images
     o.scan_threads, o.slots, o.sink_threads = scan_threads, slots, sink_threads
+    o.scan_options = scan_options
     if devices is not None:
         dv = (C.c_int32 * max(len(devices), 1))(*[int(d) for d in devices])
         o.devices, o.n_devices = C.cast(dv, C.POINTER(C.c_int32)), len(devices)

@@ -960,3 +960,85 @@ def test_corrupt_and_truncated_4k_pictures_settle_on_the_parallel_path(ctx, port
         assert dt < 0.1, (label, dt)
         n_err += st[0] != 0
     assert n_err >= 2          # the cut always ends in the reference's end-of-data error; the overwrite may re-synchronise cleanly
+
+
+# ---- progressive frames: not reference-comparable, PARITY UNPINNED ----------------------------------------------
+def test_progressive_decodes_to_the_baseline_twin(ctx, port):
+    """The reference cannot decode progressive files (its scanner rejects them, src/jpeg_scanner.cpp:425-430), so nothing of
+    the reference pins this mode.  What is checked instead: libjpeg quantises a picture the same way whether it then writes a
+    baseline or a progressive file, so the coefficients in both files are the same -- and the progressive decode (opt-in scanner,
+    pjd_k_progressive, dense back end) must give, bit for bit, the pixels the ORACLE gives for the baseline twin, with the
+    standard zigzag map on both sides (PJD_F_STANDARD_ZIGZAG: the reference's map treats an explicit zero at slot 52 specially,
+    which only a baseline stream can express).  Colour in three samplings, grey, odd sizes, restart intervals, low and high
+    quality; plus the dense coefficients themselves through pjd_batch_download_coefficients."""
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    import pjd_amd
+    rng = np.random.default_rng(77)
+    cases = []
+    for (w, h, sub, q, kw) in [(64, 48, 0, 85, {}), (101, 77, 2, 90, {}), (200, 150, 1, 60, {}), (33, 70, 2, 95, {}), (17, 9, 0, 30, {}),
+                               (128, 96, 2, 85, {"restart_marker_blocks": 5}), (96, 64, 0, 75, {"restart_marker_rows": 1}), (500, 375, 2, 92, {"optimize": True})]:
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        img = np.stack([127 + 100 * np.sin(xx / 9.0) * np.cos(yy / 13.0), 127 + 90 * np.cos(xx / 17.0), (xx + yy) * 255 / (w + h)], -1) + rng.normal(0, 12, (h, w, 3))
+        cases.append((PIL.fromarray(np.clip(img, 0, 255).astype(np.uint8), "RGB"), dict(quality=q, subsampling=sub, **kw)))
+    grey = PIL.fromarray((rng.random((45, 61)) * 255).astype(np.uint8), "L")
+    cases.append((grey, dict(quality=80)))
+    port.standard_zigzag(True)
+    try:
+        for img, kw in cases:
+            def enc(**extra):
+                bio = io.BytesIO()
+                img.save(bio, "JPEG", **kw, **extra)
+                return bio.getvalue()
+            # the twin is written WITHOUT restart markers: the reference (and so the oracle) garbles 4:2:0 + DRI (SURVEY 0.7), and
+            # restart markers do not change the coefficients
+            plain = {k: v for k, v in kw.items() if not k.startswith("restart")}
+            bio = io.BytesIO()
+            img.save(bio, "JPEG", **plain)
+            base, prog = bio.getvalue(), enc(progressive=True)
+            want = port.decode(base)
+            assert want["valid"] and want["huff_rc"] == 0
+            s = pjd_amd.Scanned(prog, options=pjd_amd.SCAN_PROGRESSIVE)
+            assert s.valid and int(s.desc.n_scans) >= 2, kw
+            s.desc.flags = int(s.desc.flags) | pjd_amd.F_STANDARD_ZIGZAG
+            with ctx.batch([s.desc]) as b:
+                b.upload(); b.decode()
+                outs, st = b.download()
+                info = b.info()
+                coef = b.coefficients(0)
+            assert st == [0] and info["n_sequential"] == 1, kw
+            assert np.array_equal(outs[0], want["rgb"]), kw
+            assert np.array_equal(coef, want["coef"]), kw
+    finally:
+        port.standard_zigzag(False)
+
+
+def test_progressive_in_a_mixed_batch_and_through_the_cli(ctx, port, tmp_path):
+    """Progressive and baseline pictures in ONE batch (each keeps its own result); the pipelined batcher with scan option;
+    `bin/decoder --progressive` writes a BMP where the plain CLI prints the reference's rejection."""
+    import io
+    import subprocess
+    import pjd_amd
+    from conftest import ROOT
+    PIL = pytest.importorskip("PIL.Image")
+    prog = golden_bytes("neg_progressive_64x48")
+    names = ["env_61x45_420_q100_opt", "big_640x480_420_q85", "gray_61x45"]
+    scanned = [pjd_amd.Scanned(golden_bytes(n)) for n in names] + [pjd_amd.Scanned(prog, options=pjd_amd.SCAN_PROGRESSIVE)]
+    outs, st = ctx.decode([s.desc for s in scanned], pjd_amd.OUT_RGB8)
+    assert st == [0, 0, 0, 0]
+    for n, o in zip(names, outs):
+        assert np.array_equal(o, port.decode(golden_bytes(n))["rgb"]), n
+    alone, _ = ctx.decode([scanned[3].desc], pjd_amd.OUT_RGB8)
+    assert np.array_equal(outs[3], alone[0])
+    ref = np.asarray(PIL.open(io.BytesIO(prog)).convert("RGB")).astype(np.int32)
+    assert np.abs(outs[3].astype(np.int32) - ref).mean() < 6        # same picture as an independent decoder's, different rounding
+    (tmp_path / "p.jpg").write_bytes(prog)
+    exe = os.path.join(ROOT, "bin", "decoder")
+    p = subprocess.run([exe, str(tmp_path / "p.jpg")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "Invalid marker during compressed data scan: 0xc4" in p.stdout and not (tmp_path / "p.bmp").exists()
+    p = subprocess.run([exe, "--progressive", str(tmp_path / "p.jpg")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and (tmp_path / "p.bmp").exists(), p.stdout
+    bmp = (tmp_path / "p.bmp").read_bytes()
+    assert bmp == pjd_amd.rgb_to_bmp(outs[3])
+    stt = pjd_amd.pipe_run(jpegs=[prog, golden_bytes("gray_61x45")], batch_images=2, slots=1, scan_options=pjd_amd.SCAN_PROGRESSIVE)
+    assert stt["n_decoded"] == 2 and stt["n_rejected"] == 0

@@ -194,3 +194,41 @@ def test_plan_info_host_only():
     assert info["n_data_units"] == 63 * 47 * 3 + 40 * 30 * 6 + 25 * 19 * 3 + 4 * 3 * 6 + 8 * 6
     assert info["n_sequential"] == 1          # 4:2:0 + DRI under the reference's restart rule
     assert info["n_subsequences"] >= (info["ecs_bytes"] - 3000) // 128
+
+
+def test_progressive_files_are_rejected_by_default_and_parsed_on_request():
+    """The reference rejects a progressive file at its first inter-scan marker (src/jpeg_scanner.cpp:425-430) and so does the
+    scanner by default -- same message, fixture neg_progressive_64x48.  With PJD_SCAN_PROGRESSIVE (not reference
+    behaviour) the same file yields its scan list: a DC-first scan over all components first, spectral selections inside 1..63,
+    successive approximation consistent from scan to scan, tables attached to every scan that reads symbols; the planner routes
+    the picture to the scan-by-scan kernel (one dense-scratch picture, no Huffman lanes)."""
+    data = golden_bytes("neg_progressive_64x48")
+    s0 = pjd_amd.Scanned(data)
+    assert not s0.valid and "Invalid marker during compressed data scan: 0xc4" in s0.log
+    s = pjd_amd.Scanned(data, options=pjd_amd.SCAN_PROGRESSIVE)
+    assert s.valid and s.log == "" and int(s.desc.flags) & pjd_amd.F_PROGRESSIVE
+    n = int(s.desc.n_scans)
+    assert n >= 4 and int(s.desc.ecs_len) == 0
+    first = s.desc.scans[0]
+    assert (first.n_comp, first.ss, first.se, first.ah) == (3, 0, 0, 0)
+    al_seen = {}
+    for k in range(n):
+        sc = s.desc.scans[k]
+        comps = tuple(sc.comp[q] for q in range(sc.n_comp))
+        assert 1 <= sc.n_comp <= 3 and sc.ss <= sc.se <= 63 and (sc.ss == 0) == (sc.se == 0)
+        assert sc.ss == 0 or sc.n_comp == 1
+        for c in comps:
+            for z in range(sc.ss, sc.se + 1):
+                prev = al_seen.get((c, z))
+                assert (sc.ah == 0 and prev is None) or (prev is not None and sc.ah == prev and sc.al == prev - 1), (k, c, z)
+                al_seen[(c, z)] = sc.al
+        if not (sc.ss == 0 and sc.ah != 0):
+            assert all(sc.table[q].set for q in range(sc.n_comp))
+        assert sc.ecs_len > 0
+    assert all(al_seen[(c, z)] == 0 for c in range(3) for z in range(64))      # every coefficient refined down to bit 0
+    info = pjd_amd.plan_info([s.desc])
+    assert info["n_sequential"] == 1 and info["n_subsequences"] == 0 and info["n_data_units"] == 4 * 3 * 6       # 64x48, 4:2:0
+    # a baseline file is the same with and without the option
+    b = golden_bytes("env_64x48_444_q85")
+    a1, a2 = pjd_amd.Scanned(b), pjd_amd.Scanned(b, options=pjd_amd.SCAN_PROGRESSIVE)
+    assert a1.valid and a2.valid and int(a2.desc.flags) == 0 and bytes(a1.ecs()) == bytes(a2.ecs())
