@@ -259,6 +259,8 @@ __device__ __forceinline__ uint32_t lut_lookup(uint32_t lbase, uint32_t tab, uin
     return e;
 }
 
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // ndu += vcc ? 1 : 0 in one instruction (the compiler emits a select and an add)
 __device__ __forceinline__ uint32_t add_flag(uint32_t v, bool f)
 {
@@ -324,6 +326,117 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
     z = 63u - (uint32_t)zb;
     jout = j;
     return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The COOPERATIVE WALKER: one lane's subsequence decoded by the whole wave (state only, same result as sync_span<true>).
+//
+// A re-sync round costs a full pass of the wave whether 64 lanes or 2 are active, because one symbol of ONE lane is a chain of
+// ~45 dependent instructions and two LDS round trips (~450 cycles alone on a SIMD).  When few lanes are left, the wave instead
+// takes them one after the other: lane k looks up the symbol that would START at bit position p + k, for the tables of the
+// current data unit and of the unit after it (64 positions x 4 tables: a handful of LDS reads per step), and a scalar loop hops
+// through the results -- v_readlane + ~8 SALU per symbol, ~12 symbols per 64-bit window.  The chain of ONE lane advances
+// several times faster, and because lanes are taken in ascending order a changed exit state is carried straight into the next
+// lane: a chain of non-merging lanes that needed one round per lane is one walk.
+// The bitstream comes from the picture's byte stream itself (contiguous across the lanes of a restart segment, so the window
+// buffer survives lane boundaries): 64 big-endian dwords per lane register `cw` (+ the following 64 in `cn`, loaded a window
+// ahead), gathered per bit position with ds_bpermute.
+// ---------------------------------------------------------------------------------------------
+#ifndef PJD_WALK_MAX
+#define PJD_WALK_MAX 8          // rounds with at most this many active lanes are walked (0: never)
+#endif
+struct WalkBuf {
+    pjd_gptr ecs;          // first byte of the picture's bitstream
+    uint32_t clamp;        // last byte offset a dword is read at (inside the zero padding after the stream)
+    uint32_t cb;           // byte offset of word 0 of `cw` (a multiple of 4)
+    uint32_t cw, cn;       // per lane: word l of the window, word 64 + l
+    uint32_t have;
+    __device__ __forceinline__ uint32_t ld(uint32_t off) const
+    {
+        off = off < clamp ? off : clamp;
+        return __builtin_bswap32(reinterpret_cast<const __attribute__((address_space(1))) UnalignedU32 *>(ecs + off)->v);
+    }
+    // make the window hold bits [pa, pa + 128) of the picture within its first 62 words
+    __device__ __forceinline__ void reach(uint32_t pa, uint32_t l)
+    {
+        cb = rfl(cb); have = rfl(have);                                        // wave-uniform by construction
+        const uint32_t rel = pa - 8u * cb;
+        if (have && pa >= 8u * cb && rel <= 1920u) return;
+        if (have && pa >= 8u * cb && rel < 2048u) {                            // slide by s <= 63 words inside (cw, cn)
+            const uint32_t s = rel >> 5, idx = l + s;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)cw);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)cn);
+            cw = idx < 64u ? a : b;
+            cb += 4u * s;
+        } else {
+            cb = (pa >> 5) * 4u;
+            cw = ld(cb + 4u * l);
+        }
+        cn = ld(cb + 256u + 4u * l);
+        have = 1;
+    }
+};
+
+// All arguments but `l` are wave-uniform.  st_col / rem_col: the checkpoint columns of the lane that is walked.
+__device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_t l, uint32_t base_bit,
+                                         uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit, uint32_t &ndu,
+                                         uint32_t *st_col, uint32_t *rem_col, uint32_t chk_bits, uint32_t &jout)
+{
+    uint32_t j = 1;
+    jout = 1;
+    if (p >= end_bit) return SPAN_END;
+    // scalar copies (intrinsic results, not loads from the context struct: selects between them stay selects)
+    const uint32_t tY = rfl(P.tY), tC1 = rfl(P.tC1), tC2 = rfl(P.tC2), nc = rfl(P.nc), dus1 = rfl(P.dus1), lbase = rfl(P.lbase);
+#define WALK_TABS(r_) ((r_) >= nc ? tY : ((r_) == 0 ? tC2 : tC1))
+#define WALK_NEXT(r_) ((r_) == 0 ? dus1 : (r_) - 1u)
+    uint32_t r = dus1 - c;                                       // units of the MCU still to come after the current one
+    int zb = 63 - (int)z;
+    uint32_t next_chk = chk_bits;
+    uint32_t lim = next_chk < end_bit ? next_chk : end_bit;
+    int res = SPAN_END;
+    for (;;) {                                                   // one step = the symbols that start in one window of 64 bit positions
+        wb.reach(base_bit + p, l);
+        const uint32_t bp = base_bit + p - 8u * rfl(wb.cb) + l, wi = bp >> 5, sh = bp & 31u;
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wi << 2), (int)wb.cw);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi + 1u) << 2), (int)wb.cw);
+        const uint32_t pk = (uint32_t)((((((uint64_t)hi) << 32) | lo) << sh) >> 32);       // the 32 bits from position p + l on
+        const uint32_t rn = WALK_NEXT(r), xa = WALK_TABS(r), xb = WALK_TABS(rn);
+        uint32_t EA = lut_lookup(lbase, xa >> 16, pk) << 16;                                 // DC | AC << 16 of the current unit ...
+        if (zb == 63) EA |= lut_lookup(lbase, xa & 0xffffu, pk);
+        const uint32_t EB = lut_lookup(lbase, xb & 0xffffu, pk) | (lut_lookup(lbase, xb >> 16, pk) << 16);       // ... and of the next
+        const uint32_t klim = lim - p < 64u ? lim - p : 64u;     // symbols must start inside the window and before `lim`
+        uint32_t k = 0, E = EA;
+        bool second = false;
+        for (;;) {
+            uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)E, (int)k);
+            e = zb == 63 ? e & 0xffffu : e >> 16;
+            k += PJD_LUT_USED(e);
+            zb -= (int)PJD_LUT_ADV(e);
+            if (zb < 0) {                                        // the unit is complete
+                ndu++; zb = 63; r = WALK_NEXT(r);
+                if (k >= klim || second) break;
+                second = true; E = EB;                           // the unit after it: its tables were looked up too
+                continue;
+            }
+            if (k >= klim) break;
+        }
+        p += k;
+        if (p >= lim) {
+            if (p >= end_bit) break;
+            const uint32_t st = (p << 14) | (r << 10) | (uint32_t)zb;                        // as sync_span: record offset r * 16 << 6
+            if (rfl(st_col[j * 64]) == st) { ndu += rfl(rem_col[j * 64]); res = SPAN_MERGED; break; }
+            if (l == 0) { st_col[j * 64] = st; rem_col[j * 64] = ndu; }
+            j++;
+            next_chk += chk_bits;
+            lim = next_chk < end_bit ? next_chk : end_bit;
+        }
+    }
+    c = dus1 - r;
+    z = 63u - (uint32_t)zb;
+    jout = j;
+    return res;
+#undef WALK_TABS
+#undef WALK_NEXT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -536,7 +649,7 @@ struct WaveState { uint32_t p_img, cz, cnt; };
 
 // Re-sync rounds inside one wave.  `changed`: this lane's exit state is new to its successor.  Lane 0 takes its
 // predecessor's exit from (ext_p, ext_cz) in the first round if `ext_new`.
-__device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g, const ChkCtx &K, WaveState &S, uint32_t changed,
+__device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g, const ChkCtx &K, WalkBuf &wb, WaveState &S, uint32_t changed,
                                             uint32_t ext_p, uint32_t ext_cz, bool ext_new, uint32_t &err_acc,
                                             unsigned long long *stats, int stat_base, uint32_t *rdbg)
 {
@@ -555,6 +668,43 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
         const uint64_t act_mask = __ballot(act);
         if (!act_mask) return true;
         const uint64_t tr0 = rdbg ? __builtin_amdgcn_s_memrealtime() : 0;
+#if PJD_WALK_MAX
+        if (__popcll(act_mask) <= PJD_WALK_MAX) {
+            // few lanes left: the wave walks them (and whatever their new exit states set in motion) one after the other
+            uint64_t mask = act_mask;
+            uint32_t walked = 0;
+            const uint32_t chk_bits = rfl(K.chk_bits);
+            const uint64_t can = __ballot(g.valid && !g.seg_first);
+            while (mask) {
+                uint32_t a = (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                uint32_t ep = rfl(ext_p), ecz = rfl(ext_cz);
+                if (a) { ep = (uint32_t)__builtin_amdgcn_readlane((int)S.p_img, (int)(a - 1)); ecz = (uint32_t)__builtin_amdgcn_readlane((int)S.cz, (int)(a - 1)); }
+                for (;;) {
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)g.base_bit, (int)a);
+                    const uint32_t endb = (uint32_t)__builtin_amdgcn_readlane((int)g.end_bit, (int)a);
+                    uint32_t p = ep - base, c = ecz >> 8, z = ecz & 255u, ndu = 0, j;
+                    uint32_t *st_col = K.state - l + a, *rem_col = K.rem - l + a;
+                    const int res = walk_lane(P, wb, l, base, p, c, z, endb, ndu, st_col, rem_col, chk_bits, j);
+                    if (l == 0) for (uint32_t i = 1; i < j; i++) rem_col[i * 64] = ndu - rem_col[i * 64];      // chk_finish
+                    walked++;
+                    const uint32_t np = p + base, ncz = (c << 8) | z;
+                    const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)S.p_img, (int)a), ocz = (uint32_t)__builtin_amdgcn_readlane((int)S.cz, (int)a);
+                    if (l == a) S.cnt = ndu;
+                    if (res == SPAN_MERGED || (np == op && ncz == ocz)) break;
+                    if (l == a) { S.p_img = np; S.cz = ncz; }
+                    // the successor has a new entry state: go on into it
+                    if (a == 63) break;
+                    if (!((can >> (a + 1)) & 1ull)) break;
+                    a++; mask &= ~(1ull << a);
+                    ep = np; ecz = ncz;
+                }
+            }
+            if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)walked); atomicAdd(stats + 12, 1ull); atomicAdd(stats + 13, (unsigned long long)walked); }
+            if (rdbg && l == 0 && iter < 24) rdbg[iter] = (0x80u << 24) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - tr0) & 0xffffffu);
+            return true;
+        }
+#endif
         if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)__popcll(act_mask)); }
         changed = 0;
         if (act) {
@@ -634,8 +784,6 @@ __device__ __forceinline__ uint64_t op_wait_flag(const uint64_t *p, bool &timeou
     timeout = timeout || !(v & OP_FLAG);
     return v & ~OP_FLAG;
 }
-
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ---------------------------------------------------------------------------------------------
 // The kernel.
@@ -765,8 +913,12 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     uint64_t entry_used = 0;
     uint32_t err_acc = 0;
     bool ok = true;
+    WalkBuf wb;
+    wb.ecs = (pjd_gptr)readfirstlane_u64((uint64_t)(B.ecs + im.ecs_off));
+    wb.clamp = rfl(im.ecs_len) + 40u;                      // >= 48 zero bytes follow every stream (pjd_plan.cpp)
+    wb.cb = 0; wb.cw = 0; wb.cn = 0; wb.have = 0;
     if (!first_is_head) entry_used = op_wait_flag(genA + w - 1, dead);
-    ok = wave_rounds(P, g, K, S, g.valid ? 1u : 0u, (uint32_t)entry_used,
+    ok = wave_rounds(P, g, K, wb, S, g.valid ? 1u : 0u, (uint32_t)entry_used,
                      (((uint32_t)(entry_used >> 32) & 255) << 8) | ((uint32_t)(entry_used >> 40) & 255), !first_is_head && !dead,
                      err_acc, B.stats, 0, B.dbg ? B.dbg + (size_t)w * 32 + 8 : nullptr);
     if (l == last_lane) op_store(genB + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
@@ -777,7 +929,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         const uint64_t truth = op_wait_flag(genB + w - 1, dead);
         if (!dead && truth != entry_used) {
             entry_used = truth;
-            ok = wave_rounds(P, g, K, S, 0u, (uint32_t)truth,
+            ok = wave_rounds(P, g, K, wb, S, 0u, (uint32_t)truth,
                              (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255), true,
                              err_acc, B.stats, 2, nullptr) && ok;
         }
