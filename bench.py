@@ -373,10 +373,11 @@ def main():
                        "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
                        "exact_kernel_images": main_rates["exact_kernel_images"],
                        "hip_graph": not args.no_graph, "batches_in_flight": nfl, "host_nproc": os.cpu_count(),
-                       "sync": dict({k: info[k] for k in ("n_huff_workgroups", "n_huff_waves", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes")},
+                       "sync": dict({k: info[k] for k in ("n_huff_workgroups", "n_huff_waves", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes", "walks", "walk_lanes")},
                                     lane_passes_per_lane=round(2.0 + info["sync_lane_passes"] / max(1, info["n_subsequences"]), 3),
                                     note="lane_passes_per_lane = speculative pass + re-sync passes + write pass, per lane (work); a wave's "
-                                         "re-sync round lasts as long as its slowest lane")},
+                                         "re-sync round lasts as long as its slowest lane; walks = rounds a wave finished cooperatively "
+                                         "(few lanes left), walk_lanes = lanes re-decoded that way (counted in sync_lane_passes too)")},
             "ecs_GBps": main_rates["ecs_GBps"], "huffman_symbols_per_s": main_rates["huffman_symbols_per_s"],
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_issue_frac": valu_issue_frac,

@@ -332,12 +332,12 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.out, P.out_buf_bytes, tot));
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->dev.imstate, (size_t)n_images, tot));
-    // wave_gen [3][n_hwave], wave_desc [n_hwave] and the ticket live in one allocation, zeroed before every launch
-    TRY_RC(dev_alloc(ctx, b->d_opstate, n_hwave * 4 + 2, tot));
-    b->opstate_bytes = (n_hwave * 4 + 2) * sizeof(uint64_t);
+    // wave_gen [PJD_GENS][n_hwave], wave_desc [n_hwave] and the ticket live in one allocation, zeroed before every launch
+    TRY_RC(dev_alloc(ctx, b->d_opstate, n_hwave * (PJD_GENS + 1) + 2, tot));
+    b->opstate_bytes = (n_hwave * (PJD_GENS + 1) + 2) * sizeof(uint64_t);
     b->dev.wave_gen = b->d_opstate;
-    b->dev.wave_desc = b->d_opstate + n_hwave * 3;
-    b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + n_hwave * 4);
+    b->dev.wave_desc = b->d_opstate + n_hwave * PJD_GENS;
+    b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + n_hwave * (PJD_GENS + 1));
     b->dev.dbg = nullptr;
     if (std::getenv("PJD_DEBUG_STATS")) TRY_RC(dev_alloc(ctx, b->dev.dbg, n_hwave * 32, tot));
     TRY_RC(dev_alloc(ctx, b->dev.stats, 16, tot));
@@ -688,6 +688,7 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     if (b->decoded && hipMemcpyAsync(st, b->dev.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->ctx->stream) == hipSuccess &&
         hipStreamSynchronize(b->ctx->stream) == hipSuccess) {
         info->sync_rounds = st[0]; info->sync_lane_passes = st[1]; info->fix_rounds = st[2]; info->fix_lane_passes = st[3];
+        info->walks = st[PJD_STAT_WALKS]; info->walk_lanes = st[PJD_STAT_WALKS + 1];
         for (int r = 0; r < PJD_FLAG_REASONS && r < 8; r++) info->flag_waves[r] = st[PJD_STAT_FLAG0 + r];
         info->n_entries = st[PJD_STAT_ENTRIES];               // entries the lanes emitted in the last decode
     }
@@ -716,6 +717,9 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
                 std::sort(cl.begin(), cl.end());
                 std::fprintf(stderr, "[pjd waves] shader clock while the waves ran: median %.2f GHz (min %.2f, max %.2f)\n", cl[nw / 2] / 160.0, cl.front() / 160.0, cl.back() / 160.0);
             }
+            std::fprintf(stderr, "[pjd back end] parser chunk iterations %llu for %llu entries in %zu workgroups (%.2f per workgroup; %.0f %% of the %d-entry slots used)\n",
+                         (unsigned long long)b->h_stats[14], (unsigned long long)b->h_stats[PJD_STAT_ENTRIES], P.iwgs.size(), (double)b->h_stats[14] / (double)(P.iwgs.size() ? P.iwgs.size() : 1),
+                         100.0 * (double)b->h_stats[PJD_STAT_ENTRIES] / ((double)(b->h_stats[14] ? b->h_stats[14] : 1) * 1024.0), 1024);
             std::fprintf(stderr, "[pjd waves] n %zu | mean(us): start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write+verify %.1f | max(us): %.1f %.1f %.1f %.1f %.1f %.1f\n",
                          nw, sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, sum[4] / n / 100, sum[5] / n / 100,
                          mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0, mx[4] / 100.0, mx[5] / 100.0);
@@ -728,7 +732,10 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
                     std::fprintf(stderr, "[pjd waves]   wave %zu: start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write %.1f\n", k,
                                  (d[k * 32] - t0) / 100.0, d[k * 32 + 1] / 100.0, d[k * 32 + 2] / 100.0, d[k * 32 + 3] / 100.0, d[k * 32 + 4] / 100.0, d[k * 32 + 5] / 100.0);
                     std::fprintf(stderr, "[pjd waves]     rounds (lanes:us):");
-                    for (int r = 0; r < 24 && d[k * 32 + 8 + r]; r++) std::fprintf(stderr, " %u:%.1f", d[k * 32 + 8 + r] >> 24, (d[k * 32 + 8 + r] & 0xffffff) / 100.0);
+                    for (int r = 0; r < 24 && d[k * 32 + 8 + r]; r++) {        // a walk (pjd_k_huffman.hip, walk_lane) is printed as w<lanes walked>
+                        const uint32_t v = d[k * 32 + 8 + r];
+                        std::fprintf(stderr, (v >> 31) ? " w%u:%.1f" : " %u:%.1f", (v >> 24) & 0x7fu, (v & 0xffffff) / 100.0);
+                    }
                     std::fprintf(stderr, "\n");
                 }
         }

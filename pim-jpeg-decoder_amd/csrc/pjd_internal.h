@@ -39,10 +39,25 @@
 #ifndef PJD_IDCT_PRIO
 #define PJD_IDCT_PRIO      0        // issue priority of the back end's waves (0..3)
 #endif
+// The cooperative walker (pjd_k_huffman.hip, walk_lane): a re-sync round with at most PjdDevImage::walk_max active lanes is finished
+// by the whole wave taking the lanes one after the other.  A walk has a start-up cost per lane (a window of the bitstream is fetched),
+// a round costs the same whatever the number of lanes, so the threshold is 8 lanes where chains are long -- subsequences shorter than
+// PJD_WALK_DENSE_MCUS MCUs' worth of this picture's stream: lanes rarely merge inside their own subsequence -- and sub_bytes >> PJD_WALK_SHIFT
+// otherwise (4 lanes at 512 bytes: lanes merge early there).  Measured in profiles/r03_experiments.md.  PJD_WALK_MAX in the environment
+// overrides it for every picture of a batch (0: never walk).
+#ifndef PJD_WALK_SHIFT
+#define PJD_WALK_SHIFT     7
+#endif
+#define PJD_WALK_DENSE     8
+#define PJD_WALK_DENSE_MCUS 4
 #define PJD_LUT_BITS       10       // first-level Huffman LUT width
 #define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
 #define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one table set in LDS; larger -> exact kernel
 #define PJD_MAX_TABLES     6        // distinct Huffman tables one image can reference (3 DC + 3 AC)
+#ifndef PJD_GENS
+#define PJD_GENS           6        // generations of a wave's published exit state (wave_gen): 0 = speculative, 1 = after its own re-sync rounds, g + 1 = after
+#endif                              // comparing its entry with generation g of its predecessor (and re-bridging if that differs); the last one is only checked.
+                                    // A chain of non-merging lanes that crosses k wave boundaries needs k + 2 generations; never a chain over the whole image.
 #define PJD_SYNC_MAX_ITERS 72       // re-sync rounds per wave before giving up (a non-merging chain moves one lane per round)
 #define PJD_DC_BLOCK       256      // lanes per DC-prediction scan block
 #define PJD_IDCT_THREADS   256
@@ -113,6 +128,7 @@ enum {
 };
 #define PJD_STAT_FLAG0 4
 #define PJD_STAT_ENTRIES 11  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
+#define PJD_STAT_WALKS   12  // cooperative walks (a wave taking over its few remaining active lanes), 13: lanes walked in them
 
 struct PjdDevImage {
     uint32_t width, height;
@@ -139,7 +155,8 @@ struct PjdDevImage {
     uint32_t tset;                     // table set (PjdDevTset) of this image
     uint32_t sub_bytes;                // subsequence size of THIS image (<= the batch's, which sizes word rows and lane regions)
     uint8_t  tbl_slot[3][2];           // [component][0=DC,1=AC] -> table slot 0..n_tables-1 of the set
-    uint8_t  pad_[2];
+    uint8_t  walk_max;                 // re-sync rounds with at most this many active lanes are walked cooperatively (0: never)
+    uint8_t  pad_;
     uint32_t pscan_base, n_pscan;      // progressive frames: their scans in PjdDevBatch::pscans
 };
 

@@ -671,7 +671,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     // before it (a DC entry counts 1), M = A at the start of its unit; zigzag slot = A - M + run.  U and A come from one
     // additive scan, M from a max scan (A never decreases).
     uint32_t run_units = 0, run_tail = 0;                       // over the chunks so far (uniform): units done, A - M at the chunk start
-    for (uint32_t it = 0; run_units < n_valid; ) {
+    uint32_t it = 0;
+    for (; run_units < n_valid; ) {
         if (n >= n_ent) {                                       // next lane of the image
             q++; n = 0;
             if (q >= lane_end) break;
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         n += cnt;
         it++;                                                   // the other copy of wagg next time
     }
+    if (B.dbg && tid == 0) atomicAdd(B.stats + 14, (unsigned long long)(it));   // PJD_DEBUG_STATS: chunk iterations of the parser
     __syncthreads();
 
 #if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 1      // timing experiments only (tools/r2_occ.sh): pictures are wrong

@@ -25,7 +25,7 @@
 //                           PJD_NCHK checkpoints of the trajectory in LDS
 //                        R  re-sync rounds: a lane restarts from its predecessor's exit state and stops as soon
 //                           as its state equals a checkpoint; states travel by wave shuffles; across waves by
-//                           published 64-bit words (three generations, never a chain over the image)
+//                           published 64-bit words (PJD_GENS generations, never a chain over the image)
 //                        C  data-unit counts: scan inside the wave, decoupled look-back over the image's waves
 //                        W  write pass from the true entry states: EVERY symbol becomes one 16-bit entry in the
 //                           lane's own region (layout: pjd_internal.h), staged through LDS and written as whole
@@ -240,6 +240,7 @@ struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided b
     uint32_t *state;       // [PJD_NCHK][64] at this lane's column
     uint32_t *rem;         // [PJD_NCHK][64]
     uint32_t chk_bits;     // checkpoint spacing
+    uint32_t walk_max;     // wave-uniform: rounds with at most this many active lanes are walked (walk_lane)
 };
 
 enum { SPAN_END = 0, SPAN_MERGED = 1 };
@@ -342,9 +343,7 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
 // buffer survives lane boundaries): 64 big-endian dwords per lane register `cw` (+ the following 64 in `cn`, loaded a window
 // ahead), gathered per bit position with ds_bpermute.
 // ---------------------------------------------------------------------------------------------
-#ifndef PJD_WALK_MAX
-#define PJD_WALK_MAX 8          // rounds with at most this many active lanes are walked (0: never)
-#endif
+// Which rounds are walked: PjdDevImage::walk_max (pjd_internal.h; chosen by the planner).
 struct WalkBuf {
     pjd_gptr ecs;          // first byte of the picture's bitstream
     uint32_t clamp;        // last byte offset a dword is read at (inside the zero padding after the stream)
@@ -396,30 +395,50 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
     int res = SPAN_END;
     for (;;) {                                                   // one step = the symbols that start in one window of 64 bit positions
         wb.reach(base_bit + p, l);
-        const uint32_t bp = base_bit + p - 8u * rfl(wb.cb) + l, wi = bp >> 5, sh = bp & 31u;
+        // Symbols must start inside the window and before `lim`: k < klim.  The chase keeps (zb << 8) + k + 128 - klim in ONE scalar:
+        // a symbol adds (bits used) - (slots advanced << 8); bit 31 then says "unit complete" (zb < 0), bit 7 "k >= klim", and
+        // the low six bits select the lane that holds position k -- so lane l looks at position (l + klim) mod 64.
+        const uint32_t klim = lim - p < 64u ? lim - p : 64u;
+        const uint32_t bp = base_bit + p - 8u * rfl(wb.cb) + ((l + klim) & 63u), wi = bp >> 5, sh = bp & 31u;
         const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wi << 2), (int)wb.cw);
         const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi + 1u) << 2), (int)wb.cw);
-        const uint32_t pk = (uint32_t)((((((uint64_t)hi) << 32) | lo) << sh) >> 32);       // the 32 bits from position p + l on
+        const uint32_t pk = (uint32_t)((((((uint64_t)hi) << 32) | lo) << sh) >> 32);       // the 32 bits from that position on
         const uint32_t rn = WALK_NEXT(r), xa = WALK_TABS(r), xb = WALK_TABS(rn);
-        uint32_t EA = lut_lookup(lbase, xa >> 16, pk) << 16;                                 // DC | AC << 16 of the current unit ...
-        if (zb == 63) EA |= lut_lookup(lbase, xa & 0xffffu, pk);
-        const uint32_t EB = lut_lookup(lbase, xb & 0xffffu, pk) | (lut_lookup(lbase, xb >> 16, pk) << 16);       // ... and of the next
-        const uint32_t klim = lim - p < 64u ? lim - p : 64u;     // symbols must start inside the window and before `lim`
-        uint32_t k = 0, E = EA;
+        // the symbol at every position under the DC and AC tables of the current unit and of the unit after it: four reads in flight
+        const uint32_t i2 = 2u * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS);
+        uint32_t e0 = lds_u16((xa & 0xffffu) + i2), e1 = lds_u16((xa >> 16) + i2), e2 = lds_u16((xb & 0xffffu) + i2), e3 = lds_u16((xb >> 16) + i2);
+        if (__builtin_expect(__any((PJD_LUT_USED(e0) == 0) | (PJD_LUT_USED(e1) == 0) | (PJD_LUT_USED(e2) == 0) | (PJD_LUT_USED(e3) == 0)), 0)) {
+            const uint32_t t2 = 2u * ((pk >> 16) & 63u);                                    // codes longer than 10 bits: second level
+            if (PJD_LUT_USED(e0) == 0) e0 = lds_u16(lbase + 2u * ((e0 >> 5) << 6) + t2);
+            if (PJD_LUT_USED(e1) == 0) e1 = lds_u16(lbase + 2u * ((e1 >> 5) << 6) + t2);
+            if (PJD_LUT_USED(e2) == 0) e2 = lds_u16(lbase + 2u * ((e2 >> 5) << 6) + t2);
+            if (PJD_LUT_USED(e3) == 0) e3 = lds_u16(lbase + 2u * ((e3 >> 5) << 6) + t2);
+        }
+#define WALK_DELTA(e_) (PJD_LUT_USED(e_) - (PJD_LUT_ADV(e_) << 8))
+        uint32_t Ddc = WALK_DELTA(e0), Dac = WALK_DELTA(e1);
+        const uint32_t DdcB = WALK_DELTA(e2), DacB = WALK_DELTA(e3);
+#undef WALK_DELTA
+        const uint32_t bias = 128u - klim;
+        uint32_t st = ((uint32_t)zb << 8) + bias;
         bool second = false;
         for (;;) {
-            uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)E, (int)k);
-            e = zb == 63 ? e & 0xffffu : e >> 16;
-            k += PJD_LUT_USED(e);
-            zb -= (int)PJD_LUT_ADV(e);
-            if (zb < 0) {                                        // the unit is complete
-                ndu++; zb = 63; r = WALK_NEXT(r);
-                if (k >= klim || second) break;
-                second = true; E = EB;                           // the unit after it: its tables were looked up too
-                continue;
+            if ((st >> 8) == 63u) {                              // the unit's DC symbol
+                st += (uint32_t)__builtin_amdgcn_readlane((int)Ddc, (int)(st & 63u));
+                if (st & 0x80000080u) {
+                    if ((int)st >= 0) break;                     // k >= klim
+                    goto unit_done;                              // (no DC table advances past the unit; kept general)
+                }
             }
-            if (k >= klim) break;
+            do st += (uint32_t)__builtin_amdgcn_readlane((int)Dac, (int)(st & 63u)); while (!(st & 0x80000080u));
+            if ((int)st >= 0) break;                             // k >= klim inside the unit
+        unit_done:
+            ndu++; r = WALK_NEXT(r);
+            st = (63u << 8) | (st & 0xffu);                      // the unit is complete: DC expected
+            if ((st & 0x80u) || second) break;
+            second = true; Ddc = DdcB; Dac = DacB;               // the unit after it: its tables were looked up too
         }
+        zb = (int)(st >> 8);
+        const uint32_t k = (st & 0xffu) - bias;
         p += k;
         if (p >= lim) {
             if (p >= end_bit) break;
@@ -668,8 +687,7 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
         const uint64_t act_mask = __ballot(act);
         if (!act_mask) return true;
         const uint64_t tr0 = rdbg ? __builtin_amdgcn_s_memrealtime() : 0;
-#if PJD_WALK_MAX
-        if (__popcll(act_mask) <= PJD_WALK_MAX) {
+        if ((uint32_t)__popcll(act_mask) <= K.walk_max) {
             // few lanes left: the wave walks them (and whatever their new exit states set in motion) one after the other
             uint64_t mask = act_mask;
             uint32_t walked = 0;
@@ -700,11 +718,10 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
                     ep = np; ecz = ncz;
                 }
             }
-            if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)walked); atomicAdd(stats + 12, 1ull); atomicAdd(stats + 13, (unsigned long long)walked); }
-            if (rdbg && l == 0 && iter < 24) rdbg[iter] = (0x80u << 24) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - tr0) & 0xffffffu);
+            if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)walked); atomicAdd(stats + PJD_STAT_WALKS, 1ull); atomicAdd(stats + PJD_STAT_WALKS + 1, (unsigned long long)walked); }
+            if (rdbg && l == 0 && iter < 24) rdbg[iter] = ((0x80u | (walked & 0x7fu)) << 24) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - tr0) & 0xffffffu);   // walked lanes
             return true;
         }
-#endif
         if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)__popcll(act_mask)); }
         changed = 0;
         if (act) {
@@ -795,9 +812,10 @@ __device__ __forceinline__ uint64_t op_wait_flag(const uint64_t *p, bool &timeou
 //
 //   * workgroups take their index from a ticket counter, so every wave a wave waits for has already started
 //     (waits can always be satisfied; they are bounded anyway and poison the image on time-out);
-//   * generation A of a wave = the speculative exit of its last lane, the guess its successor's first lane
-//     bridges from; generation B = that lane's exit after the wave's own re-sync rounds; the successor compares
-//     B with the guess it used and re-bridges from B if they differ, then publishes generation C -- never a chain
+//   * generation 0 of a wave = the speculative exit of its last lane, the guess its successor's first lane
+//     bridges from; generation 1 = that lane's exit after the wave's own re-sync rounds; generation g + 1 = its exit after the
+//     wave compared the entry it used with generation g of its predecessor and re-bridged if they differ (PJD_GENS
+//     generations: a chain that crosses k wave boundaries needs k + 2) -- never a chain
 //     across the image; at the very end a wave checks that the entry it used is what its predecessor finally
 //     produced (else: exact kernel);
 //   * data-unit counts (segmented: a restart segment's first subsequence resets to the segment's first
@@ -854,7 +872,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
 
     const uint64_t ts0 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     const uint64_t tc0 = B.dbg ? __builtin_amdgcn_s_memtime() : 0;          // shader clock: with ts0..ts5 (100 MHz) it gives the clock the chip held
-    uint64_t *genA = B.wave_gen, *genB = B.wave_gen + B.n_hwave, *genC = B.wave_gen + 2 * (size_t)B.n_hwave;
+    uint64_t *genA = B.wave_gen, *genB = B.wave_gen + B.n_hwave;      // generation g of wave w: B.wave_gen[g * n_hwave + w]
     // ---- lane geometry
     LaneGeom g;
     g.valid = l < hw.n_lanes;
@@ -890,6 +908,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     K.state = area + l;
     K.rem = area + PJD_NCHK * 64 + l;
     K.chk_bits = sub_bytes * 8 / PJD_NCHK;
+    K.walk_max = rfl(im.walk_max);
     for (int j = 0; j < PJD_NCHK; j++) { K.state[j * 64] = 0xffffffffu; K.rem[j * 64] = 0; }
     const bool first_is_head = __shfl((uint32_t)g.seg_first, 0) != 0;     // lane 0 starts a restart segment: no predecessor wave
     const uint32_t last_lane = hw.n_lanes - 1;
@@ -924,17 +943,21 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     if (l == last_lane) op_store(genB + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
     const uint64_t ts2 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 
-    // ---- stitch: redo this wave's bridges from the predecessor's re-synchronised exit if the guess was wrong
-    if (!first_is_head && !dead) {
-        const uint64_t truth = op_wait_flag(genB + w - 1, dead);
-        if (!dead && truth != entry_used) {
-            entry_used = truth;
-            ok = wave_rounds(P, g, K, wb, S, 0u, (uint32_t)truth,
-                             (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255), true,
-                             err_acc, B.stats, 2, nullptr) && ok;
+    // ---- stitch: compare the entry this wave used with its predecessor's next generation; redo the bridges from it if it differs
+    //      (a walk of lane 0's chain, usually a few hundred bytes); publish the own exit as the next generation.  Every generation
+    //      resolves one more wave boundary that a chain of non-merging lanes crosses.
+    for (uint32_t gen = 1; gen + 1 < PJD_GENS; gen++) {
+        if (!first_is_head && !dead) {
+            const uint64_t truth = op_wait_flag(B.wave_gen + (size_t)gen * B.n_hwave + w - 1, dead);
+            if (!dead && truth != entry_used) {
+                entry_used = truth;
+                ok = wave_rounds(P, g, K, wb, S, 0u, (uint32_t)truth,
+                                 (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255), true,
+                                 err_acc, B.stats, 2, nullptr) && ok;
+            }
         }
+        if (l == last_lane) op_store(B.wave_gen + (size_t)(gen + 1) * B.n_hwave + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
     }
-    if (l == last_lane) op_store(genC + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
     if (!ok) flag |= 1u << PJD_FLAG_NOSYNC;
     const uint64_t ts3 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 
@@ -1067,7 +1090,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     if (g.valid) B.lane_info[g.q] = li;
     // the entry this wave was synchronised with must be what its predecessor finally produced
     if (!first_is_head && !dead) {
-        const uint64_t fin = op_wait_flag(genC + w - 1, dead);
+        const uint64_t fin = op_wait_flag(B.wave_gen + (size_t)(PJD_GENS - 1) * B.n_hwave + w - 1, dead);
         if (fin != entry_used) flag |= 1u << PJD_FLAG_STITCH;
     }
     if (B.dbg && l == 0) {

@@ -30,12 +30,12 @@ struct PjdDevBatch {
     int32_t *status;                     // per image
     PjdDevImState *imstate;              // per image: first entropy-coding error / earliest unresolved irregularity of this decode
     // Huffman kernel scratch (zeroed before every launch)
-    uint64_t *wave_gen;                  // [3][n_hwave]: exit state of a wave's last lane | flag; generations A / B / C
+    uint64_t *wave_gen;                  // [PJD_GENS][n_hwave]: exit state of a wave's last lane | flag, one word per generation (pjd_internal.h)
     uint64_t *wave_desc;                 // per Huffman wave: look-back descriptor (status | poison | head | units)
     uint32_t *ticket;                    // workgroup index dispenser
     uint32_t *dbg;                       // PJD_DEBUG_STATS: per wave, 8 timestamps (10 ns units); else null
     unsigned long long *stats;           // [16] diagnostics: 0 re-sync rounds, 1 lane passes in them, 2 / 3 the same for the stitch
-                                         //      stage, PJD_STAT_FLAG0.. waves that flagged their image, by reason
+                                         //      stage, PJD_STAT_FLAG0.. waves that flagged their image, by reason, 12 / 13 cooperative walks and the lanes walked in them
     uint32_t n_images, n_tsets, n_lanes, n_hwave, n_hwg, n_iwg, n_dcblk;
     uint32_t sub_bytes;                  // Huffman subsequence size of this batch
     uint32_t word_rows;                  // PJD_WORD_ROWS(sub_bytes)

@@ -323,6 +323,14 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             }
         }
         g.sub_bytes = SBi;
+        {   // which re-sync rounds the wave walks (pjd_internal.h)
+            const uint64_t n_mcu_img = (uint64_t)g.mcux * g.mcuy ? (uint64_t)g.mcux * g.mcuy : 1;
+            const uint64_t bpm = d.ecs_len / n_mcu_img;                                   // bytes of stream per MCU, whole picture
+            uint32_t wm = SBi >> PJD_WALK_SHIFT;
+            if ((uint64_t)SBi <= PJD_WALK_DENSE_MCUS * bpm && wm < PJD_WALK_DENSE) wm = PJD_WALK_DENSE;
+            if (const char *e = std::getenv("PJD_WALK_MAX")) { const int v = std::atoi(e); wm = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
+            g.walk_max = (uint8_t)wm;
+        }
         if (SBi > sb_max) sb_max = SBi;
         if (!sequential) {
             for (uint32_t k = seg_lo; k < seg_hi; k++) {

@@ -741,6 +741,39 @@ def test_config4_per_gpu_batch_of_8192(ctx, port):
     assert all(same), [sample[k] for k, ok in enumerate(same) if not ok][:10]
 
 
+# ---- the cooperative walker (pjd_k_huffman.hip, walk_lane) ---------------------------------------------------------------------
+def test_cooperative_walk_equals_plain_rounds(monkeypatch):
+    """Re-sync rounds with few active lanes are finished by the whole wave walking the lanes one after the other.  The walk must
+    produce what the plain rounds produce: same pictures, same coefficients, same entry count, no flagged wave -- on a dense 4:2:0
+    picture (long non-merging chains), a picture with restart intervals, a grey one and a picture whose Huffman codes exceed the
+    first-level table -- and it must actually run (walks > 0) unless switched off (PJD_WALK_MAX=0)."""
+    import pjd_amd
+    synth = _synth()
+    D = synth.DENSE_DETAIL
+    pics = [synth.make(1536, 1024, 11, quality=97, subsampling=synth.SUB_420, detail=D, optimize=True),
+            synth.make(640, 480, 12, quality=95, subsampling=synth.SUB_444, restart_interval=7, detail=D, optimize=True),
+            synth.make(800, 600, 13, quality=96, subsampling=synth.SUB_GREY, detail=D, optimize=True),
+            golden_bytes("huff_longtail_96x64_444"), golden_bytes("big_640x480_420_q85")]
+    res = {}
+    for shift in ("dflt", "32", "0"):
+        monkeypatch.setenv("PJD_WALK_MAX", shift) if shift != "dflt" else monkeypatch.delenv("PJD_WALK_MAX", raising=False)
+        c = pjd_amd.Context(0)
+        try:
+            scs = [pjd_amd.Scanned(b) for b in pics]
+            with c.batch([s.desc for s in scs]) as b:
+                b.upload(); b.decode(); b.sync()
+                info = b.info()
+                outs, st = b.download()
+                coefs = [hashlib.sha256(np.ascontiguousarray(b.coefficients(i)).tobytes()).hexdigest() for i in range(len(pics))]
+            res[shift] = ([o.tobytes() for o in outs], st, coefs, info["n_entries"], info["walks"], info["walk_lanes"], sum(info["flag_waves"]), info["n_fallback"])
+        finally:
+            c.close()
+    assert res["dflt"][:4] == res["0"][:4] == res["32"][:4]
+    assert res["0"][4] == 0 and res["0"][5] == 0
+    assert res["dflt"][4] > 0 and res["dflt"][5] >= res["dflt"][4] and res["32"][5] >= res["dflt"][5]
+    assert all(r[6] == 0 and r[7] == 0 for r in res.values()), {k: r[3:] for k, r in res.items()}
+
+
 # ---- the multi-rank rehearsal shape (round-2 incident, DESIGN 5a) --------------------------------------------------------------
 def test_shard_batch_and_empty_batch_replayed_keep_their_state(ctx, port):
     """The shape on which a replayed 128-byte runtime memset node once left non-zero words in the statistics buffer: a batch that
