@@ -355,20 +355,21 @@ struct WalkBuf {
         off = off < clamp ? off : clamp;
         return __builtin_bswap32(reinterpret_cast<const __attribute__((address_space(1))) UnalignedU32 *>(ecs + off)->v);
     }
-    // make the window hold bits [pa, pa + 128) of the picture within its first 62 words
-    __device__ __forceinline__ void reach(uint32_t pa, uint32_t l)
+    // make the window hold bits [pa, pa + 96) of the picture within its first 62 words; when it has to move, word 0 becomes the word of
+    // bit `keep` <= pa (the oldest position the caller may still come back to: the start of the lane it is in)
+    __device__ __forceinline__ void reach(uint32_t pa, uint32_t l, uint32_t keep)
     {
         cb = rfl(cb); have = rfl(have);                                        // wave-uniform by construction
-        const uint32_t rel = pa - 8u * cb;
-        if (have && pa >= 8u * cb && rel <= 1920u) return;
-        if (have && pa >= 8u * cb && rel < 2048u) {                            // slide by s <= 63 words inside (cw, cn)
+        if (have && pa >= 8u * cb && pa - 8u * cb <= 1920u) return;
+        const uint32_t rel = keep - 8u * cb;
+        if (have && keep >= 8u * cb && rel < 2048u) {                          // slide by s <= 63 words inside (cw, cn)
             const uint32_t s = rel >> 5, idx = l + s;
             const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)cw);
             const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx & 63u) << 2), (int)cn);
             cw = idx < 64u ? a : b;
             cb += 4u * s;
         } else {
-            cb = (pa >> 5) * 4u;
+            cb = (keep >> 5) * 4u;
             cw = ld(cb + 4u * l);
         }
         cn = ld(cb + 256u + 4u * l);
@@ -394,7 +395,7 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
     uint32_t lim = next_chk < end_bit ? next_chk : end_bit;
     int res = SPAN_END;
     for (;;) {                                                   // one step = the symbols that start in one window of 64 bit positions
-        wb.reach(base_bit + p, l);
+        wb.reach(base_bit + p, l, base_bit + p);
         // Symbols must start inside the window and before `lim`: k < klim.  The chase keeps (zb << 8) + k + 128 - klim in ONE scalar:
         // a symbol adds (bits used) - (slots advanced << 8); bit 31 then says "unit complete" (zb < 0), bit 7 "k >= klim", and
         // the low six bits select the lane that holds position k -- so lane l looks at position (l + klim) mod 64.
