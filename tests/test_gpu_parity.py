@@ -774,6 +774,19 @@ def test_cooperative_walk_equals_plain_rounds(monkeypatch):
     assert all(r[6] == 0 and r[7] == 0 for r in res.values()), {k: r[3:] for k, r in res.items()}
 
 
+@pytest.mark.parametrize("walk_max", ["64", "1"])
+def test_fixtures_and_random_streams_with_the_walker_forced(ctx, port, monkeypatch, walk_max):
+    """The reference-pinned checks once more with the walker's threshold forced: 64 = EVERY re-sync round of every picture is a
+    cooperative walk (restart segments, every sampling mode, grey, tables with long codes, truncated and corrupted streams all go
+    through walk_lane), 1 = only single chains.  Same expectations as the plain tests: BMP and coefficient hashes from the
+    reference's own code, 240 random pictures and 200 randomly damaged ones against the oracle."""
+    monkeypatch.setenv("PJD_WALK_MAX", walk_max)
+    test_decode_bmp_batch_matches_reference_hashes(ctx, "fast")
+    test_coefficients_match_reference_hashes(ctx, "fast")
+    test_random_streams_one_batch_match_oracle(ctx, port)
+    test_random_corrupted_streams_match_oracle(ctx, port)
+
+
 # ---- the multi-rank rehearsal shape (round-2 incident, DESIGN 5a) --------------------------------------------------------------
 def test_shard_batch_and_empty_batch_replayed_keep_their_state(ctx, port):
     """The shape on which a replayed 128-byte runtime memset node once left non-zero words in the statistics buffer: a batch that
