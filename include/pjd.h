@@ -179,6 +179,8 @@ typedef struct pjd_batch_info {
                                           0 invalid symbol, 1 irregular segment end / phase, 2 re-sync did not converge,
                                           3 wave boundary did not stitch, 4 wait timed out, 5 lane output overflow,
                                           6 write pass did not reproduce the synchronised state                     */
+    uint32_t huff_lds_bytes;           /* LDS of one entropy-decode workgroup: the largest table set of the batch + wave areas   */
+    uint32_t reserved_;
     uint64_t walks, walk_lanes;        /* last decode: re-sync rounds that a wave finished as a cooperative walk (few lanes left: the
                                           whole wave decodes one lane's subsequence several times faster), and the lanes walked */
 } pjd_batch_info;

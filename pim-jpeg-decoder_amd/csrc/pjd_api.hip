@@ -681,6 +681,7 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     info->n_entropy_errors = b->n_entropy_errors;
     info->sub_bytes = P.sub_bytes;
     info->n_table_sets = (uint32_t)P.tsets.size();
+    info->huff_lds_bytes = (uint32_t)(P.max_lut_bytes + PJD_HUFF_WAVES * (PJD_WAVE_LDS + PJD_PHASE_LDS) + 16);
     info->n_huff_waves = P.hwaves.size();
     // on the batch's own stream into page-locked memory: a plain hipMemcpy would wait for every other stream of the
     // device (it made the slots of the pipelined batcher run in lockstep, profiles/r02_pcie.md)
@@ -759,6 +760,7 @@ int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pj
     info->n_sequential = (int32_t)P.seq_images.size();
     info->sub_bytes = P.sub_bytes;
     info->n_table_sets = (uint32_t)P.tsets.size();
+    info->huff_lds_bytes = (uint32_t)(P.max_lut_bytes + PJD_HUFF_WAVES * (PJD_WAVE_LDS + PJD_PHASE_LDS) + 16);
     info->n_huff_waves = P.hwaves.size();
     info->n_huff_workgroups = P.hwgs.size();
     return PJD_OK;
