@@ -50,8 +50,9 @@
 #endif
 #define PJD_WALK_DENSE     8
 #define PJD_WALK_DENSE_MCUS 4
-#define PJD_LUT_BITS       10       // first-level Huffman LUT width
-#define PJD_L1_BYTES       (2 << PJD_LUT_BITS)   // one first-level table: 1024 x u16
+#define PJD_LUT_BITS       9        // first-level Huffman LUT width
+#define PJD_L2_BITS        (16 - PJD_LUT_BITS)    // a second-level table is indexed by the bits after the prefix
+#define PJD_L1_BYTES       (4 << PJD_LUT_BITS)   // one first-level table: 512 x u32 (low half: the symbol; high half: the symbol PAIR, below)
 #define PJD_LUT_LDS_MAX    (6 * PJD_L1_BYTES + 8192)  // decode tables of one table set in LDS; larger -> exact kernel
 #define PJD_MAX_TABLES     6        // distinct Huffman tables one image can reference (3 DC + 3 AC)
 #ifndef PJD_GENS
@@ -180,9 +181,10 @@ struct PjdDevScan {
 // One table set = the deduplicated Huffman tables of an image; images with identical sets share one (a batch of
 // files written with the Annex-K tables has a single set), and so can the waves of one Huffman workgroup.
 // Decode-ready form, built on the device by pjd_k_build_tables, one blob per set:
-//   [table 0 L1][table 1 L1]...[table n-1 L1][second-level regions, 64 u16 per long prefix]
-// L1 is indexed by the next PJD_LUT_BITS bits.  Entry (u16), round-3 layout -- every field the per-symbol loops need comes out
-// with one AND or one bit-field extract, and the zigzag bookkeeping is ONE subtraction (see PJD_LUT_ADV):
+//   [table 0 L1][table 1 L1]...[table n-1 L1][second-level regions, 128 u16 per long prefix]
+// L1 is indexed by the next PJD_LUT_BITS (9) bits and holds 32-bit entries; the LOW half describes the symbol that starts there --
+// every field the per-symbol loops need comes out with one AND or one bit-field extract, and the zigzag bookkeeping is ONE
+// subtraction (see PJD_LUT_ADV):
 //   bits  4..0  bits consumed by the symbol (code length + value bits), 1..27; 0 marks a pointer entry (below)
 //   bits 10..5  "advance": run + 1 for an AC run/size symbol, 1 for a DC symbol, 33 for an EOB
 //   bit  11     EOB (AC tables only).  Bits 11..5 read as ONE 7-bit number are the slots the symbol uses up -- 97 for an EOB,
@@ -193,22 +195,30 @@ struct PjdDevScan {
 //               14 = the reference's "symbol 0xFF": no code starts with these bits (then 16 bits are consumed, as its
 //                    get_next_symbol does), or the table really holds the symbol 0xFF (jpeg_scanner.cpp:470,490)
 //               15 = a DC size > 11 / an AC size > 10 (jpeg_scanner.cpp:474,506)
-//   pointer entry (bits 4..0 == 0): codes with this 10-bit prefix are longer than 10 bits; bits 15..5 = u16 index (relative to the
-//               blob) / 64 of the prefix's 64-entry second-level table, indexed by the following 6 bits; entries there have the
-//               first form with code lengths 11..16.
+//   pointer entry (bits 4..0 == 0): codes with this 9-bit prefix are longer than 9 bits; bits 15..5 = u16 index (relative to the
+//               blob) / 128 of the prefix's 128-entry second-level table (u16 entries of the form above with code lengths 10..16),
+//               indexed by the following 7 bits.
+// The HIGH half of an L1 entry of an AC table describes the PAIR "this symbol and the one after it" where the 9 bits hold the
+// first symbol whole (code and value bits), it is a valid run/size symbol (not an EOB), and the rest of the 9 bits determine the next code
+// (any valid AC symbol, an EOB too; its value bits may lie outside):
+//   bits 20..16 bits consumed by both symbols (2..27+; 0: no pair here)        bits 27..21 slots both use up (advance 1 + advance 2)
+// The state-only passes take a pair in ONE step when the first symbol neither completes the unit nor reaches the next checkpoint /
+// subsequence end: dense streams average 5 bits per symbol, 60 % of the steps there are pairs (profiles/r03_experiments.md).
 // Canonical codes keep all long codes in one contiguous range of prefixes [p0, p1), so the second level
-// costs 128 bytes per long prefix (Annex K tables: 5 prefixes for an AC table, 0..1 for a DC table).
+// costs 256 bytes per long prefix.
 struct PjdDevTset {
     uint32_t lut_off16;                // blob offset in PjdDevBatch::luts, 16-byte units
     uint32_t lut_bytes;                // multiple of 16
     uint32_t n_tables;
     uint16_t l2_off[PJD_MAX_TABLES];   // second-level region of table k: first u16 index, relative to the blob
-    uint16_t l2_p0[PJD_MAX_TABLES];    // 10-bit prefixes [p0, p1) hold codes longer than PJD_LUT_BITS
+    uint16_t l2_p0[PJD_MAX_TABLES];    // 9-bit prefixes [p0, p1) hold codes longer than PJD_LUT_BITS
     uint16_t l2_p1[PJD_MAX_TABLES];
 };
 #define PJD_LUT_USED(e)  ((e) & 31u)
 #define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 97 for an EOB
-#define PJD_LUT_SIZE(e)  ((e) >> 12)              // of a 16-bit entry
+#define PJD_LUT_SIZE(e)  (((e) >> 12) & 15u)
+#define PJD_LUT_PAIR_USED(e)  (((e) >> 16) & 31u)  // of an L1 entry: 0 = no pair
+#define PJD_LUT_PAIR_ADV(e)   (((e) >> 21) & 127u)
 #define PJD_LUT_EOB      0x0800u
 #define PJD_LUT_BADSYM   14u
 #define PJD_LUT_BADLEN   15u

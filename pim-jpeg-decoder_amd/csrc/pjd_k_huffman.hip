@@ -10,8 +10,9 @@
 // everything below.
 //
 //   pjd_k_build_tables   raw (offsets, symbols) tables -> two-level decode table per TABLE SET (images with the
-//                        same Huffman tables share one): 10-bit first level, one 64-entry second-level table
-//                        per 10-bit prefix that holds longer codes; an entry already carries bits consumed /
+//                        same Huffman tables share one): 9-bit first level (32-bit entries: the symbol, and the PAIR of
+//                        symbols where both fit), one 128-entry second-level table
+//                        per 9-bit prefix that holds longer codes; an entry already carries bits consumed /
 //                        run / size / EOB / error (semantics of reference generate_codes / get_next_symbol /
 //                        the size limits of decode_MCU_component, reference src/jpeg_scanner.cpp:438-520)
 //   pjd_k_lane_words     the bitstream of every lane as big-endian 32-bit words counted from the lane's first
@@ -45,7 +46,7 @@
 #include "../../include/pjd.h"
 
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
-static_assert(PJD_LUT_BITS == 10, "second level is indexed by the 6 bits after a 10-bit prefix");
+static_assert(PJD_LUT_BITS + PJD_L2_BITS == 16 && PJD_L1_BYTES == (4 << PJD_LUT_BITS), "two-level table geometry");
 static_assert(PJD_HUFF_LANES == 64, "one wave per 64 lanes");
 
 #define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSYM)    // no code: consume 16 bits (as the reference's get_next_symbol)
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
     if (slot >= T.n_tables || T.lut_bytes == 0) return;
     const PjdDevHuffRaw &r = B.raw_tables[(size_t)ts * PJD_MAX_TABLES + slot];
     uint16_t *blob = reinterpret_cast<uint16_t *>(B.luts + (size_t)T.lut_off16 * 16);
-    uint16_t *L1 = blob + slot * (PJD_L1_BYTES / 2);
+    uint32_t *L1 = reinterpret_cast<uint32_t *>(blob + slot * (PJD_L1_BYTES / 2));
     const uint32_t l2_off = T.l2_off[slot], p0 = T.l2_p0[slot], p1 = T.l2_p1[slot];
     const bool is_ac = r.is_ac != 0;
     __shared__ uint32_t first[17];
@@ -91,24 +92,33 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
     }
     if (tid < 17) offs[tid] = r.offsets[tid];
     __syncthreads();
+    // the symbol whose code is the leading bits of `bits` (`nbits` of them are known); 0 if none is determined by them.  Shortest match wins, as the reference's scan
+    auto match = [&](uint32_t bits, uint32_t nbits, uint32_t lo, uint32_t hi) -> uint32_t {
+        for (uint32_t len = lo; len <= hi && len <= nbits; len++) {
+            const uint32_t c = bits >> (nbits - len);
+            const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
+            if (c >= first[len] && d < cnt) return lut_entry(len, r.symbols[offs[len - 1] + d], is_ac);
+        }
+        return 0u;
+    };
     for (uint32_t idx = tid; idx < (1u << PJD_LUT_BITS); idx += 256) {
-        uint32_t e = (idx >= p0 && idx < p1) ? (((l2_off + (idx - p0) * 64) >> 6) << 5) : LUT_BAD;      // pointer entry: bits 4..0 == 0
-        for (uint32_t len = 1; len <= PJD_LUT_BITS; len++) {     // shortest match wins, as the reference's scan
-            const uint32_t c = idx >> (PJD_LUT_BITS - len);
-            const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
-            if (c >= first[len] && d < cnt) { e = lut_entry(len, r.symbols[offs[len - 1] + d], is_ac); break; }
+        uint32_t e = (idx >= p0 && idx < p1) ? (((l2_off + ((idx - p0) << PJD_L2_BITS)) >> PJD_L2_BITS) << 5) : LUT_BAD;      // pointer entry: bits 4..0 == 0
+        const uint32_t m = match(idx, PJD_LUT_BITS, 1, PJD_LUT_BITS);
+        if (m) e = m;
+        // the pair: this symbol whole inside the 9 bits, a valid run/size symbol, and the bits after it determine the next code
+        uint32_t pair = 0;
+        if (is_ac && m && !(m & PJD_LUT_EOB) && PJD_LUT_SIZE(m) < PJD_LUT_BADSYM && PJD_LUT_USED(m) < PJD_LUT_BITS) {
+            const uint32_t rest = PJD_LUT_BITS - PJD_LUT_USED(m);
+            const uint32_t m2 = match(idx & ((1u << rest) - 1u), rest, 1, rest);
+            if (m2 && PJD_LUT_SIZE(m2) < PJD_LUT_BADSYM && PJD_LUT_USED(m) + PJD_LUT_USED(m2) <= 31u)
+                pair = (PJD_LUT_USED(m) + PJD_LUT_USED(m2)) | ((PJD_LUT_ADV(m) + PJD_LUT_ADV(m2)) << 5);
         }
-        L1[idx] = (uint16_t)e;
+        L1[idx] = (e & 0xffffu) | (pair << 16);
     }
-    for (uint32_t j = tid; j < (p1 - p0) * 64; j += 256) {
-        const uint32_t w16 = (p0 << 6) + j;
-        uint32_t e = LUT_BAD;
-        for (uint32_t len = PJD_LUT_BITS + 1; len <= 16; len++) {
-            const uint32_t c = w16 >> (16 - len);
-            const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
-            if (c >= first[len] && d < cnt) { e = lut_entry(len, r.symbols[offs[len - 1] + d], is_ac); break; }
-        }
-        blob[l2_off + j] = (uint16_t)e;
+    for (uint32_t j = tid; j < ((p1 - p0) << PJD_L2_BITS); j += 256) {
+        const uint32_t w16 = (p0 << PJD_L2_BITS) + j;
+        const uint32_t m = match(w16, 16, PJD_LUT_BITS + 1, 16);
+        blob[l2_off + j] = (uint16_t)(m ? m : LUT_BAD);
     }
 }
 
@@ -191,6 +201,7 @@ struct BitWin {
 // derived from the extern array makes the compiler add that base -- a link-time constant it cannot fold -- on every access.
 __device__ __forceinline__ uint32_t lds_abs(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
 __device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(a); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(a); }
 typedef uint32_t pjd_v2u32 __attribute__((ext_vector_type(2)));
 typedef uint32_t pjd_v4u32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_u32x2(uint32_t a)
@@ -251,14 +262,17 @@ __device__ __forceinline__ void chk_finish(const ChkCtx &K, uint32_t j, uint32_t
     for (uint32_t i = 1; i < j; i++) K.rem[i * 64] = ndu - K.rem[i * 64];
 }
 
-__device__ __forceinline__ uint32_t lut_lookup(uint32_t lbase, uint32_t tab, uint32_t pk)
+// The L1 entry for the next bits (32 bits: symbol | pair << 16), or the second-level entry (16 bits: no pair) for a code longer than 9 bits
+__device__ __forceinline__ uint32_t lut_lookup_pair(uint32_t lbase, uint32_t tab, uint32_t pk)
 {
-    uint32_t e = lds_u16(tab + 2 * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS));
-    // code longer than 10 bits (a pointer entry consumes no bits): one more read, in the 64-entry table of this 10-bit prefix
+    uint32_t e = lds_u32(tab + 4 * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS));
+    // code longer than 9 bits (a pointer entry consumes no bits): one more read, in the 128-entry table of this 9-bit prefix
     if (__builtin_expect(PJD_LUT_USED(e) == 0, 0))
-        e = lds_u16(lbase + 2 * (((e >> 5) << 6) + ((pk >> 16) & 63u)));
+        e = lds_u16(lbase + 2 * ((((e >> 5) & 0x7ffu) << PJD_L2_BITS) + ((pk >> 16) & ((1u << PJD_L2_BITS) - 1u))));
     return e;
 }
+// the symbol alone (the low half)
+__device__ __forceinline__ uint32_t lut_lookup(uint32_t lbase, uint32_t tab, uint32_t pk) { return lut_lookup_pair(lbase, tab, pk) & 0xffffu; }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -300,13 +314,18 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
         const uint32_t pk = w.peek();
         const uint2 nx = lds_u32x2(ra);                                     // what follows this unit: issued beside the table lookup
         const uint32_t tab = (zb == 63) ? (x & 0xffffu) : (x >> 16);
-        const uint32_t e = lut_lookup(P.lbase, tab, pk);
-        const uint32_t used = PJD_LUT_USED(e);
+        const uint32_t e = lut_lookup_pair(P.lbase, tab, pk);
+        // two symbols in this step where the table holds the pair (AC tables only), the first one leaves the unit open and the
+        // second one still starts before the next checkpoint / the subsequence's end -- else the first alone
+        const uint32_t u1 = PJD_LUT_USED(e), u12 = PJD_LUT_PAIR_USED(e);
+        const int z1 = zb - (int)PJD_LUT_ADV(e);
+        const bool pair = u12 != 0 && z1 >= 0 && p + u1 < lim;
+        const uint32_t used = pair ? u12 : u1;
         w.drop(used);
         p += used;
         // state update (reference src/jpeg_scanner.cpp:469-518): a DC symbol advances one slot and never carries the EOB bit; a
         // run past slot 63 ends the unit here (the write pass reports it)
-        zb -= (int)PJD_LUT_ADV(e);
+        zb = pair ? zb - (int)PJD_LUT_PAIR_ADV(e) : z1;
         const bool done = zb < 0;                                           // EOB, or the unit's last slot was filled
         zb = done ? 63 : zb;
         ra = done ? nx.y : ra;
@@ -406,14 +425,14 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
         const uint32_t pk = (uint32_t)((((((uint64_t)hi) << 32) | lo) << sh) >> 32);       // the 32 bits from that position on
         const uint32_t rn = WALK_NEXT(r), xa = WALK_TABS(r), xb = WALK_TABS(rn);
         // the symbol at every position under the DC and AC tables of the current unit and of the unit after it: four reads in flight
-        const uint32_t i2 = 2u * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS);
-        uint32_t e0 = lds_u16((xa & 0xffffu) + i2), e1 = lds_u16((xa >> 16) + i2), e2 = lds_u16((xb & 0xffffu) + i2), e3 = lds_u16((xb >> 16) + i2);
+        const uint32_t i4 = 4u * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS);
+        uint32_t e0 = lds_u32((xa & 0xffffu) + i4), e1 = lds_u32((xa >> 16) + i4), e2 = lds_u32((xb & 0xffffu) + i4), e3 = lds_u32((xb >> 16) + i4);   // (the symbol: low half)
         if (__builtin_expect(__any((PJD_LUT_USED(e0) == 0) | (PJD_LUT_USED(e1) == 0) | (PJD_LUT_USED(e2) == 0) | (PJD_LUT_USED(e3) == 0)), 0)) {
-            const uint32_t t2 = 2u * ((pk >> 16) & 63u);                                    // codes longer than 10 bits: second level
-            if (PJD_LUT_USED(e0) == 0) e0 = lds_u16(lbase + 2u * ((e0 >> 5) << 6) + t2);
-            if (PJD_LUT_USED(e1) == 0) e1 = lds_u16(lbase + 2u * ((e1 >> 5) << 6) + t2);
-            if (PJD_LUT_USED(e2) == 0) e2 = lds_u16(lbase + 2u * ((e2 >> 5) << 6) + t2);
-            if (PJD_LUT_USED(e3) == 0) e3 = lds_u16(lbase + 2u * ((e3 >> 5) << 6) + t2);
+            const uint32_t t2 = 2u * ((pk >> 16) & ((1u << PJD_L2_BITS) - 1u));             // codes longer than 9 bits: second level
+            if (PJD_LUT_USED(e0) == 0) e0 = lds_u16(lbase + 2u * (((e0 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
+            if (PJD_LUT_USED(e1) == 0) e1 = lds_u16(lbase + 2u * (((e1 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
+            if (PJD_LUT_USED(e2) == 0) e2 = lds_u16(lbase + 2u * (((e2 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
+            if (PJD_LUT_USED(e3) == 0) e3 = lds_u16(lbase + 2u * (((e3 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
         }
 #define WALK_DELTA(e_) (PJD_LUT_USED(e_) - (PJD_LUT_ADV(e_) << 8))
         uint32_t Ddc = WALK_DELTA(e0), Dac = WALK_DELTA(e1);

@@ -189,8 +189,8 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             std::memset(&T, 0, sizeof T);
             T.n_tables = (uint32_t)nt;
             P.tables.resize((size_t)(ts + 1) * PJD_MAX_TABLES, PjdDevHuffRaw());
-            // decode-table layout (pjd_internal.h): first-level tables, then one 64-entry second-level table per
-            // 10-bit prefix that holds codes longer than 10 bits.  Over-subscribed tables (not a prefix code) and
+            // decode-table layout (pjd_internal.h): first-level tables, then one 128-entry second-level table per
+            // 9-bit prefix that holds codes longer than 9 bits.  Over-subscribed tables (not a prefix code) and
             // tables whose long codes need more LDS than PJD_LUT_LDS_MAX go to the exact kernel.
             bool ok = true;
             uint32_t lut_bytes = (uint32_t)nt * PJD_L1_BYTES;
@@ -212,12 +212,13 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                     code = (code + cnt) << 1;
                 }
                 const uint32_t end16 = code >> 1;
-                uint32_t p0 = end10 < 1024 ? end10 : 1024, p1 = (end16 + 63) >> 6;
-                if (p1 > 1024) p1 = 1024;
+                const uint32_t np = 1u << PJD_LUT_BITS;
+                uint32_t p0 = end10 < np ? end10 : np, p1 = (end16 + (1u << PJD_L2_BITS) - 1) >> PJD_L2_BITS;
+                if (p1 > np) p1 = np;
                 if (p1 < p0 || !ok) p1 = p0;
                 T.l2_p0[k] = (uint16_t)p0; T.l2_p1[k] = (uint16_t)p1;
                 T.l2_off[k] = (uint16_t)(lut_bytes / 2);
-                lut_bytes += (p1 - p0) * 128;
+                lut_bytes += (p1 - p0) * (2u << PJD_L2_BITS);
                 if (lut_bytes > PJD_LUT_LDS_MAX) ok = false;
             }
             T.lut_bytes = ok ? (uint32_t)align_up(lut_bytes, 16) : 0;
