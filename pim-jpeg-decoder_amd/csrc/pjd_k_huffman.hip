@@ -426,37 +426,49 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
         const uint32_t rn = WALK_NEXT(r), xa = WALK_TABS(r), xb = WALK_TABS(rn);
         // the symbol at every position under the DC and AC tables of the current unit and of the unit after it: four reads in flight
         const uint32_t i4 = 4u * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS);
-        uint32_t e0 = lds_u32((xa & 0xffffu) + i4), e1 = lds_u32((xa >> 16) + i4), e2 = lds_u32((xb & 0xffffu) + i4), e3 = lds_u32((xb >> 16) + i4);   // (the symbol: low half)
-        if (__builtin_expect(__any((PJD_LUT_USED(e0) == 0) | (PJD_LUT_USED(e1) == 0) | (PJD_LUT_USED(e2) == 0) | (PJD_LUT_USED(e3) == 0)), 0)) {
-            const uint32_t t2 = 2u * ((pk >> 16) & ((1u << PJD_L2_BITS) - 1u));             // codes longer than 9 bits: second level
-            if (PJD_LUT_USED(e0) == 0) e0 = lds_u16(lbase + 2u * (((e0 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
-            if (PJD_LUT_USED(e1) == 0) e1 = lds_u16(lbase + 2u * (((e1 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
-            if (PJD_LUT_USED(e2) == 0) e2 = lds_u16(lbase + 2u * (((e2 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
-            if (PJD_LUT_USED(e3) == 0) e3 = lds_u16(lbase + 2u * (((e3 >> 5) & 0x7ffu) << PJD_L2_BITS) + t2);
-        }
-#define WALK_DELTA(e_) (PJD_LUT_USED(e_) - (PJD_LUT_ADV(e_) << 8))
-        uint32_t Ddc = WALK_DELTA(e0), Dac = WALK_DELTA(e1);
+        const uint32_t e0 = lds_u32((xa & 0xffffu) + i4), e1 = lds_u32((xa >> 16) + i4), e2 = lds_u32((xb & 0xffffu) + i4), e3 = lds_u32((xb >> 16) + i4);   // (the symbol: low half)
+        // A position whose code is longer than 9 bits (a pointer entry) gets the mark WALK_PTR instead of its delta: the chase stops
+        // there and the ONE second-level entry it needs is fetched then (long codes are rare on the path; they are not among 256 lookups).
+#define WALK_PTR 0x40000000u
+#define WALK_DELTA(e_) (PJD_LUT_USED(e_) ? PJD_LUT_USED(e_) - (PJD_LUT_ADV(e_) << 8) : WALK_PTR)
+        uint32_t Ddc = WALK_DELTA(e0), Dac = WALK_DELTA(e1), Edc = e0, Eac = e1;
         const uint32_t DdcB = WALK_DELTA(e2), DacB = WALK_DELTA(e3);
 #undef WALK_DELTA
+        // st carries the mark (bit 30) and no other flag: replace it by the delta of the symbol's second-level entry
+#define WALK_FIX(E_)                                                                                                        \
+        do {                                                                                                                \
+            const uint32_t ep_ = (uint32_t)__builtin_amdgcn_readlane((int)(E_), (int)(st & 63u));                           \
+            const uint32_t pl_ = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)(st & 63u));                             \
+            const uint32_t e2_ = rfl(lds_u16(lbase + 2u * ((((ep_ >> 5) & 0x7ffu) << PJD_L2_BITS) + ((pl_ >> 16) & ((1u << PJD_L2_BITS) - 1u)))));   \
+            st = st - WALK_PTR + (PJD_LUT_USED(e2_) - (PJD_LUT_ADV(e2_) << 8));                                             \
+        } while (0)
         const uint32_t bias = 128u - klim;
         uint32_t st = ((uint32_t)zb << 8) + bias;
         bool second = false;
         for (;;) {
             if ((st >> 8) == 63u) {                              // the unit's DC symbol
                 st += (uint32_t)__builtin_amdgcn_readlane((int)Ddc, (int)(st & 63u));
+                if ((int)st >= 0 && (st & WALK_PTR)) WALK_FIX(Edc);
                 if (st & 0x80000080u) {
                     if ((int)st >= 0) break;                     // k >= klim
                     goto unit_done;                              // (no DC table advances past the unit; kept general)
                 }
             }
-            do st += (uint32_t)__builtin_amdgcn_readlane((int)Dac, (int)(st & 63u)); while (!(st & 0x80000080u));
+            for (;;) {
+                do st += (uint32_t)__builtin_amdgcn_readlane((int)Dac, (int)(st & 63u)); while (!(st & 0xC0000080u));
+                if ((int)st < 0 || !(st & WALK_PTR)) break;
+                WALK_FIX(Eac);
+                if (st & 0x80000080u) break;
+            }
             if ((int)st >= 0) break;                             // k >= klim inside the unit
         unit_done:
             ndu++; r = WALK_NEXT(r);
             st = (63u << 8) | (st & 0xffu);                      // the unit is complete: DC expected
             if ((st & 0x80u) || second) break;
-            second = true; Ddc = DdcB; Dac = DacB;               // the unit after it: its tables were looked up too
+            second = true; Ddc = DdcB; Dac = DacB; Edc = e2; Eac = e3;       // the unit after it: its tables were looked up too
         }
+#undef WALK_FIX
+#undef WALK_PTR
         zb = (int)(st >> 8);
         const uint32_t k = (st & 0xffu) - bias;
         p += k;
