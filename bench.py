@@ -145,7 +145,7 @@ def cpu_baseline(jpegs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of about 0.5 s on the default workload)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: a timed region of about 0.6 s on the default workload)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--images", type=int, default=1024)
