@@ -267,6 +267,11 @@ int  pjd_split_decode(const pjd_image_desc *desc, const int32_t *devices, int n_
 int  pjd_split_plan(const pjd_image_desc *desc, int world, int rank, pjd_image_desc *shard, uint64_t *seg_scratch,
                     uint64_t *byte_lo, uint64_t *byte_hi, uint32_t *first_mcu, uint32_t *last_mcu);
 void pjd_split_release(void);          /* drops the cached RCCL communicators                               */
+/* Diagnostic: the RCCL leg of pjd_split_decode on ONE device -- librccl is loaded, a one-rank communicator created, `bytes` bytes of
+ * a pattern broadcast (root 0) from one HBM buffer into another on the library's stream, the result compared, the communicator
+ * destroyed.  Exercises exactly the calls pjd_split_decode makes (ncclCommInitAll / ncclGroupStart / ncclBroadcast / ncclGroupEnd /
+ * ncclCommDestroy) on boxes that have a single GPU.  0: ok; PJD_E_STATE: librccl cannot be loaded; PJD_E_HIP: a call failed.          */
+int  pjd_split_rccl_selftest(int device_ordinal, uint64_t bytes);
 
 /* ---- the literal DPU contract ---------------------------------------------- *
  * metadata: n_dpus x u32[276]   (decoder_host.cpp:156-178 index map)

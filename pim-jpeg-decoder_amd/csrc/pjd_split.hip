@@ -168,6 +168,36 @@ int pjd_split_plan(const pjd_image_desc *desc, int world, int rank, pjd_image_de
     return PJD_OK;
 }
 
+int pjd_split_rccl_selftest(int device_ordinal, uint64_t bytes)
+{
+    if (!rccl().ok) return PJD_E_STATE;          // librccl cannot be loaded
+    if (bytes == 0) bytes = 20480;
+    pjd_ctx *ctx = nullptr;
+    int rc = pjd_open(device_ordinal, &ctx);
+    if (rc != PJD_OK) return rc;
+    hipStream_t s = (hipStream_t)pjd_stream(ctx);
+    uint8_t *src = nullptr, *dst = nullptr;
+    std::vector<uint8_t> pat(bytes), back(bytes, 0);
+    for (uint64_t i = 0; i < bytes; i++) pat[i] = (uint8_t)(i * 131u + 7u);
+    rccl_comm comm = nullptr;
+    const int dev = device_ordinal;
+    bool ok = hipSetDevice(dev) == hipSuccess && hipMalloc((void **)&src, bytes) == hipSuccess && hipMalloc((void **)&dst, bytes) == hipSuccess &&
+              hipMemcpyAsync(src, pat.data(), bytes, hipMemcpyHostToDevice, s) == hipSuccess && hipMemsetAsync(dst, 0, bytes, s) == hipSuccess;
+    if (ok) ok = rccl().CommInitAll(&comm, 1, &dev) == 0;
+    if (ok) {
+        int nr = rccl().GroupStart();
+        if (nr == 0) nr = rccl().Broadcast(src, dst, bytes, kNcclUint8, 0, comm, s);
+        const int ne = rccl().GroupEnd();
+        ok = nr == 0 && ne == 0;
+    }
+    if (ok) ok = hipMemcpyAsync(back.data(), dst, bytes, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && back == pat;
+    if (comm) rccl().CommDestroy(comm);
+    if (src) hipFree(src);
+    if (dst) hipFree(dst);
+    pjd_close(ctx);
+    return ok ? PJD_OK : PJD_E_HIP;
+}
+
 void pjd_split_release(void)
 {
     std::lock_guard<std::mutex> l(g_comm_m);

@@ -938,6 +938,25 @@ def test_split_decode_broadcasts_with_rccl_and_handles_the_odd_cases(ctx, port, 
     pjd_amd.dev_lib().pjd_split_release()
 
 
+def test_rccl_leg_of_split_decode_on_one_device():
+    """pjd_split_decode's collective needs two distinct GPUs; this pool's boxes have one.  The calls it makes -- dlopen(librccl),
+    ncclCommInitAll, ncclGroupStart / ncclBroadcast / ncclGroupEnd on the library's stream, ncclCommDestroy -- run here on a
+    one-rank communicator (pjd_split_rccl_selftest: a 20 KB blob broadcast from one HBM buffer into another and compared).
+    In a child process with a time limit: communicator set-up is the one thing here that talks to the network stack."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import pjd_amd, ctypes as C; L = pjd_amd.dev_lib(); "
+            "L.pjd_split_rccl_selftest.restype = C.c_int; L.pjd_split_rccl_selftest.argtypes = [C.c_int, C.c_uint64]; "
+            "print('rc', L.pjd_split_rccl_selftest(0, 20480))") % os.path.join(os.path.dirname(HERE), "pim-jpeg-decoder_amd", "python")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL communicator set-up did not finish in 240 s on this box")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rc 0" in r.stdout or "rc -5" in r.stdout, (r.stdout, r.stderr[-1000:])      # -5: librccl not loadable here
+    if "rc -5" in r.stdout:
+        pytest.skip("librccl cannot be loaded on this box")
+
+
 def test_cli_split_writes_the_same_bmp(tmp_path, monkeypatch):
     """bin/decoder --split --devices 0,0,0 <file>: the CLI's route into pjd_split_decode (one picture, several devices)."""
     import shutil
