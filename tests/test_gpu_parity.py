@@ -957,6 +957,39 @@ def test_rccl_leg_of_split_decode_on_one_device():
         pytest.skip("librccl cannot be loaded on this box")
 
 
+def test_python_split_harness_over_the_nccl_backend_one_rank():
+    """The bench harness's exchange for BASELINE config 5 (pjd_amd.parallel.distribute_image) with torch.distributed's nccl backend
+    (= RCCL) and tensors in HBM: one rank is all a one-GPU box allows, so the descriptor broadcast runs through RCCL and the
+    scatter degenerates to the local copy (the isend / recv leg needs two GPUs; the gloo tests cover its logic).  The shard it
+    yields decodes to the oracle's picture.  In a child process with a time limit."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        import numpy as np, torch, torch.distributed as dist
+        import pjd_amd
+        from pjd_amd import parallel
+        from conftest import golden_bytes
+        import oracle_lib
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        data = golden_bytes("rstrow_200x150_444_opt")
+        sc = pjd_amd.Scanned(data)
+        d, keep, nblob = parallel.distribute_image(sc, src=0, device=torch.device("cuda", 0))
+        ctx = pjd_amd.Context(0)
+        outs, st = ctx.decode([d], pjd_amd.OUT_RGB8)
+        want = oracle_lib.Port().decode(data)["rgb"]
+        print("ok" if st == [0] and np.array_equal(outs[0], want) and nblob > 0 else "mismatch")
+        dist.destroy_process_group()
+    """) % (os.path.join(os.path.dirname(HERE), "pim-jpeg-decoder_amd", "python"), HERE)
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the nccl process group did not come up in 300 s on this box")
+    assert r.returncode == 0 and "ok" in r.stdout.split(), (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_cli_split_writes_the_same_bmp(tmp_path, monkeypatch):
     """bin/decoder --split --devices 0,0,0 <file>: the CLI's route into pjd_split_decode (one picture, several devices)."""
     import shutil
