@@ -326,6 +326,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.coef, P.dense_du * 64, tot));
     TRY_RC(dev_alloc(ctx, b->dev.ent, (size_t)P.n_ent, tot));
     TRY_RC(dev_alloc(ctx, b->dev.lane_info, P.subs.size(), tot));
+    TRY_RC(dev_alloc(ctx, b->dev.ghead, P.subs.size() * (size_t)(P.lane_cap / PJD_GROUP), tot));
     TRY_RC(dev_alloc(ctx, b->dev.lane_dc, P.subs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_blk, (size_t)P.n_dcblk * 8, tot));
     TRY_RC(dev_alloc(ctx, b->dev.marks, P.iwgs.size(), tot));

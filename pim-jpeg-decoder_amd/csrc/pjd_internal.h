@@ -260,10 +260,17 @@ struct PjdDevIdctWg {                  // one IDCT/colour workgroup = one coeffi
 // what a Huffman lane leaves behind for the back end (written at the end of its write pass)
 struct PjdDevLaneInfo {
     uint32_t n_ent;                    // entries in the lane's region
-    uint32_t seg_first;                // 1: the lane starts a restart segment (DC predictors are zero there)
+    uint32_t first_du;                 // bits 27..0: image-relative index of the data unit the lane's first entry belongs to (a unit may span lanes);
+                                       // bit 31: the lane starts a restart segment (DC predictors are zero there)
     uint16_t dc_sum[3];                // sum of the DC differences decoded in this lane, per component (mod 2^16)
     uint16_t pad_;
 };
+#define PJD_LANE_SEG_FIRST 0x80000000u
+// Group heads (PjdDevBatch::ghead): entries are parsed in GROUPS of PJD_GROUP consecutive entries of one lane, one back-end thread each
+// (pjd_k_idct_colour_lanes).  To start in the middle of a lane the thread needs where the group's first entry stands: the write pass
+// leaves one word per group, `[units completed in this lane before the entry : 24][zigzag slot the entry fills from : 8]` (slot 0: the
+// entry is a unit's DC difference; else the AC coefficient of the entry lands on slot + run).  Lane q's heads: ghead[q * (lane_cap / PJD_GROUP) + g].
+#define PJD_GROUP 16
 
 // DC predictors at the start of a lane, from the scan over PjdDevLaneInfo::dc_sum (pjd_k_lane_dc_*)
 struct PjdDevLaneDc {

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_lane_dc_local(PjdDevBatch 
     uint32_t vy = 0, vcb = 0, vcr = 0, head = 0;
     if (q < B.n_lanes) {
         const PjdDevLaneInfo li = B.lane_info[q];
-        vy = li.dc_sum[0]; vcb = li.dc_sum[1]; vcr = li.dc_sum[2]; head = li.seg_first;
+        vy = li.dc_sum[0]; vcb = li.dc_sum[1]; vcr = li.dc_sum[2]; head = li.first_du >> 31;
     }
     sy[tid] = vy; scb[tid] = vcb; scr[tid] = vcr; sf[tid] = head;
     __syncthreads();
@@ -584,6 +584,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 // ---------------------------------------------------------------------------------------------
 #define PJD_PARSE_PER_THREAD 4
 #define PJD_PARSE_CHUNK (PJD_IDCT_THREADS * PJD_PARSE_PER_THREAD)
+#ifndef PJD_PARSE_GROUPS
+#define PJD_PARSE_GROUPS 1            // 1: one thread per group of 16 entries (group heads from the write pass); 0: the round-2 parser (scans over 1024-entry chunks)
+#endif
 
 // Inclusive scans over the 64 lanes of a wave with DPP moves (VALU only, no LDS round trips): shifts inside each row of
 // 16 lanes, then the last lane of a row broadcast into the following rows.  Values are unsigned; 0 is the identity of both.
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     const PjdDevMark mark = B.marks[blockIdx.x];
     const uint32_t lane_end = im.lane_base + im.n_lane;
     uint32_t q = mark.lane, n = mark.ent_off;
+    (void)n;
     if (n_valid == 0) { q = im.lane_base; n = 0; }              // nothing to parse: the mark may never have been written
     else if (q < im.lane_base || q >= lane_end) return;         // never on a verified image; keeps a stale mark harmless
     // predictors at the first unit: lane start (block-relative or absolute) + block carry + sums inside the lane
@@ -664,6 +668,92 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 #pragma unroll
         for (int c = 0; c < 3; c++) pred0[c] = (uint32_t)ld.dc_in[c] + (ld.abs ? 0u : (uint32_t)carry[c]) + mark.acc[c];
     }
+#if PJD_PARSE_GROUPS
+    __syncthreads();
+    // ---- parse: entries -> tile, one thread per GROUP of PJD_GROUP consecutive entries of a lane.  The write pass left with every
+    // group where its first entry stands (PjdDevBatch::ghead: units completed in the lane before it, slot it fills from) and with
+    // every lane the unit its first entry belongs to (PjdDevLaneInfo::first_du), so a thread walks its 16 entries on its own: a DC
+    // entry opens a unit, an AC entry lands on slot + run, the LAST bit closes the unit -- no scans over entries, no barriers
+    // between chunks (round 2: two wave scans and two barriers per 1024 entries, ~70 instructions per entry against ~25 here).
+    // Lanes are taken in windows of 32 (a range of 96 units spans 3-4 lanes of a dense picture, ~20 of 128 bytes); the window's
+    // table -- groups before each lane, its first unit relative to the range, its entry count -- lives where mcu_xy will.
+    {
+        uint32_t *ltab = mcu_xy;                               // [0..31] groups before lane i of the window, [32..63] first_du - U0, [64..95] entries
+        const uint32_t U0 = wg.first_mcu * dus;
+        const uint32_t g0 = mark.ent_off / PJD_GROUP;          // the range starts in this group of lane q
+        const uint32_t gcap = B.lane_cap / PJD_GROUP;
+        // where the NEXT range starts (its mark) bounds this one; usable when every unit of this range was decoded
+        uint32_t q_end = 0xffffffffu, g_end = 0;
+        if (n_valid == n_du && blockIdx.x + 1 < im.iwg_base + im.n_iwg) {
+            const PjdDevMark nm = B.marks[blockIdx.x + 1];
+            if (nm.lane >= q && nm.lane < lane_end) { q_end = nm.lane; g_end = nm.ent_off / PJD_GROUP; }
+        }
+        for (uint32_t qw = q; n_valid != 0; qw += 32) {
+            bool more = false;
+            if (tid < 32) {
+                const uint32_t ql = qw + tid;
+                uint32_t ng = 0, fd = 0, ne = 0;
+                if (ql < lane_end) {
+                    const PjdDevLaneInfo li = B.lane_info[ql];
+                    fd = (li.first_du & 0x0fffffffu) - U0;                  // "negative" for the lane the range starts in
+                    ne = li.n_ent;
+                    const bool in = ql == q || (int)fd < (int)n_valid;
+                    if (in && ql <= q_end) {
+                        const uint32_t gs = ql == q ? g0 : 0u, all = (ne + PJD_GROUP - 1) / PJD_GROUP;
+                        uint32_t ge = ql == q_end ? (g_end + 1 < all ? g_end + 1 : all) : all;
+                        ng = ge > gs ? ge - gs : 0u;
+                    }
+                    more = in && ql < q_end;
+                }
+                uint32_t inc = ng;
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if ((int)tid >= off) inc += t; }
+                ltab[tid] = inc - ng; ltab[32 + tid] = fd; ltab[64 + tid] = ne;
+                if (tid == 31) { wagg[0][0][0] = inc; wagg[0][0][1] = more ? 1u : 0u; }   // groups in the window; the lane behind it may belong to the range too
+            }
+            __syncthreads();
+            const uint32_t G = wagg[0][0][0];
+            const bool again = wagg[0][0][1] != 0 && qw + 32 < lane_end;
+            for (uint32_t w = tid; w < G; w += PJD_IDCT_THREADS) {
+                uint32_t li_ = 0;                                           // last lane of the window whose groups start at or before w
+#pragma unroll
+                for (uint32_t step = 16; step != 0; step >>= 1) if (ltab[li_ + step] <= w) li_ += step;
+                const uint32_t ql = qw + li_;
+                const uint32_t g = w - ltab[li_] + (ql == q ? g0 : 0u);
+                const uint32_t ne = ltab[64 + li_];
+                const uint32_t cnt = ne - g * PJD_GROUP < PJD_GROUP ? ne - g * PJD_GROUP : PJD_GROUP;
+                const uint32_t head = B.ghead[(size_t)ql * gcap + g];
+                uint32_t u = ltab[32 + li_] + (head >> 8);                  // unit of the group's first entry, relative to the range
+                uint32_t slot = head & 63u;                                 // 0: that entry is a DC difference
+                const uint4 *src = reinterpret_cast<const uint4 *>(B.ent + (size_t)ql * B.lane_cap + (size_t)g * PJD_GROUP);
+                const uint4 r0 = src[0], r1 = src[1];                       // 32 bytes, 32-byte aligned (lane_cap and PJD_GROUP are multiples of 16 entries)
+                const uint32_t wds[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int k = 0; k < PJD_GROUP; k++) {
+                    const uint32_t e = (k & 1) ? wds[k >> 1] >> 16 : wds[k >> 1] & 0xffffu;
+                    if ((uint32_t)k >= cnt) { }
+                    else if (slot == 0) {                                        // DC difference: 12-bit two's complement
+                        if (u < n_valid) dcraw[u] = (int)(((e & 0x7ffu) | ((e >> 1) & 0x800u)) << 20) >> 20;
+                        slot = 1;
+                    } else {
+                        const uint32_t s_ = slot + (e >> 12);
+                        const bool term = (e & 0xf7ffu) == 0;                    // EOB: completes the unit, stores nothing
+                        if (!term && s_ < 64 && u < n_valid) {
+                            const int val = (int)(e << 21) >> 21;
+                            const uint32_t comp = comp_of[u];
+                            if (s_ == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
+                            else { const uint32_t qe = qz[comp][s_]; tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu); }
+                        }
+                        slot = s_ + 1;
+                        if (e & PJD_ENT_LAST) { u++; slot = 0; }
+                    }
+                }
+            }
+            __syncthreads();
+            if (!again) break;
+        }
+    }
+#else
     uint32_t n_ent = B.lane_info[q].n_ent;
     __syncthreads();
 
@@ -770,6 +860,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     if (B.dbg && tid == 0) atomicAdd(B.stats + 14, (unsigned long long)(it));   // PJD_DEBUG_STATS: chunk iterations of the parser
     __syncthreads();
 
+#endif
 #if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 1      // timing experiments only (tools/r2_occ.sh): pictures are wrong
     if (tile[0][0] == 12345) B.out[0] = 1;
     return;

@@ -48,6 +48,7 @@
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
 static_assert(PJD_LUT_BITS + PJD_L2_BITS == 16 && PJD_L1_BYTES == (4 << PJD_LUT_BITS), "two-level table geometry");
 static_assert(PJD_HUFF_LANES == 64, "one wave per 64 lanes");
+static_assert(PJD_STAGE_ENTRIES == PJD_GROUP, "a group head is written with every flush of the staging buffer");
 
 #define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSYM)    // no code: consume 16 bits (as the reference's get_next_symbol)
 
@@ -505,6 +506,8 @@ struct OutCtx {
     uint32_t mark_next;    // index of the next mark this lane would write
     uint32_t lane_q;
     uint32_t overflow;
+    uint32_t *ghead;       // this lane's group heads (pjd_internal.h)
+    uint32_t D_in;         // the lane's first data unit
 };
 
 // 16 dwords of the lane's staging column -> 64 bytes of its region
@@ -595,6 +598,7 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
         const uint4 cur = lds_u32x4(P.self(P.dus1 - c));
         S.x = cur.x; S.ra = cur.y; S.mA = cur.z; S.mB = cur.w;
     }
+    O.ghead[0] = z;                                                          // group 0: no unit completed yet, the first entry fills from slot z
     for (;;) {
         if (S.p >= end_bit || D >= D_end) break;
         const uint32_t e0 = write_step(P.lbase, w, S, D, O);
@@ -606,6 +610,7 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
         if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {
             stage_flush(O, O.n - PJD_STAGE_ENTRIES);
             if (O.n + PJD_STAGE_ENTRIES > O.cap) { O.overflow = 1; break; }
+            O.ghead[O.n / PJD_GROUP] = ((D - O.D_in) << 8) | (63u - (uint32_t)S.zb);           // where the next group's first entry stands
         }
     }
     if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
@@ -632,8 +637,9 @@ struct Careful {
 };
 
 __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col, uint32_t p, uint32_t c, uint32_t z,
-                                          uint32_t end_bit, uint32_t eof_rel, uint32_t D, uint32_t D_end, uint16_t *region, uint32_t cap, Careful &R)
+                                          uint32_t end_bit, uint32_t eof_rel, uint32_t D, uint32_t D_end, uint16_t *region, uint32_t cap, uint32_t *ghead, Careful &R)
 {
+    const uint32_t D_in = D;
     BitWin w;
     w.init(wave_words, col, p);
     uint4 cur = lds_u32x4(P.self(P.dus1 - c));      // .x tables, .y own record, .z / .w DC-sum selectors of the current unit
@@ -642,6 +648,7 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
     const bool at_end = eof_rel != 0xffffffffu;
     while (D < D_end && (p < end_bit || at_end)) {
         const bool is_dc = zb == 63;
+        if ((R.n & (PJD_GROUP - 1)) == 0 && R.n < cap) ghead[R.n / PJD_GROUP] = ((D - D_in) << 8) | (63u - (uint32_t)zb);      // group head (pjd_internal.h)
         const uint32_t pk = w.peek();
         const uint4 nx = lds_u32x4(cur.y);
         const uint32_t e = lut_lookup(P.lbase, is_dc ? (cur.x & 0xffffu) : (cur.x >> 16), pk);
@@ -660,7 +667,7 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
         }
         if (bad) {
             R.cls = bad; R.p_err = p; R.D_err = D; R.in_dc = is_dc ? 1u : 0u;
-            if (!is_dc && R.n < cap) region[R.n++] = (uint16_t)PJD_ENT_LAST;       // the unit keeps what it has
+            if (!is_dc && R.n < cap) region[R.n++] = (uint16_t)PJD_ENT_LAST;       // the unit keeps what it has (its group head, if it opens a group, was written above)
             break;
         }
         const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size);
@@ -1050,7 +1057,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     const uint32_t prev_p = __shfl_up(S.p_img, 1), prev_cz = __shfl_up(S.cz, 1);
     const uint32_t prev_v = __shfl_up(v, 1), prev_f = __shfl_up(f, 1);      // inclusive counts of the lane before: this lane's first unit
     PjdDevLaneInfo li;
-    li.n_ent = 0; li.seg_first = g.seg_first ? 1u : 0u; li.dc_sum[0] = li.dc_sum[1] = li.dc_sum[2] = 0; li.pad_ = 0;
+    li.n_ent = 0; li.first_du = g.seg_first ? PJD_LANE_SEG_FIRST : 0u; li.dc_sum[0] = li.dc_sum[1] = li.dc_sum[2] = 0; li.pad_ = 0;
     if (g.valid && !dead) {
         // first data unit of this lane = the (saturating) counts before it; not "inclusive - own count": the lane that holds the
         // picture's last unit also counts whatever follows it, and its inclusive value may have saturated
@@ -1076,6 +1083,9 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
             O.ru = im.idct_mcus * dus;
             O.marks = B.marks + im.iwg_base;
             O.lane_q = g.q;
+            O.ghead = B.ghead + (size_t)g.q * (B.lane_cap / PJD_GROUP);
+            O.D_in = D_in;
+            li.first_du |= D_in;
             {   // the next data unit that STARTS in this lane and opens an IDCT workgroup's range
                 const uint32_t first_du = im.first_mcu * dus;
                 const uint32_t d_next = (z == 0) ? D_in : D_in + 1;                       // first unit starting here
@@ -1096,7 +1106,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 // an entropy-coding error of the TRUE decode (this lane started from the true state): find it exactly, keep what
                 // precedes it, report it by position -- the picture's verdict takes the first one (pjd_k_image_verdict)
                 Careful R;
-                careful_span(P, g.words, g.col, p0, c0, z0, g.end_bit, eof_lane ? g.seg_end_bit : 0xffffffffu, D_in, D_end, O.region, O.cap, R);
+                careful_span(P, g.words, g.col, p0, c0, z0, g.end_bit, eof_lane ? g.seg_end_bit : 0xffffffffu, D_in, D_end, O.region, O.cap, O.ghead, R);
                 if (R.cls) {
                     li.n_ent = R.n;
                     li.dc_sum[0] = (uint16_t)R.dcA; li.dc_sum[1] = (uint16_t)(R.dcA >> 16); li.dc_sum[2] = (uint16_t)R.dcB;
