@@ -63,7 +63,7 @@
 #define PJD_DC_BLOCK       256      // lanes per DC-prediction scan block
 #define PJD_IDCT_THREADS   256
 #ifndef PJD_IDCT_MAX_DU
-#define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup (<= PJD_IDCT_THREADS)
+#define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup (<= PJD_IDCT_THREADS); with the group parser (round 3): 72 / 90 / 96 -> 0.59 / 0.53 / 0.525 ms on cfg3
 #endif
 #define PJD_COEF_SENTINEL  (-32768) // "slot 52 was visited with an explicit 0" (zigzag quirk)
 

@@ -625,6 +625,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     __shared__ uint32_t s52[PJD_IDCT_MAX_DU]; // entry at slot 52, if the unit has one
     __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
     __shared__ uint32_t wagg[2][4][2];        // per chunk parity, per wave: (units completed << 16 | sum of run+1), max unit-start mark
+    __shared__ uint32_t ltab[96];             // group parser: the window's lane table
 
 #if PJD_IDCT_PRIO
     __builtin_amdgcn_s_setprio(PJD_IDCT_PRIO);
@@ -676,9 +677,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     // entry opens a unit, an AC entry lands on slot + run, the LAST bit closes the unit -- no scans over entries, no barriers
     // between chunks (round 2: two wave scans and two barriers per 1024 entries, ~70 instructions per entry against ~25 here).
     // Lanes are taken in windows of 32 (a range of 96 units spans 3-4 lanes of a dense picture, ~20 of 128 bytes); the window's
-    // table -- groups before each lane, its first unit relative to the range, its entry count -- lives where mcu_xy will.
+    // table holds the groups before each lane, its first unit relative to the range and its entry count.
     {
-        uint32_t *ltab = mcu_xy;                               // [0..31] groups before lane i of the window, [32..63] first_du - U0, [64..95] entries
+        // ltab: [0..31] groups before lane i of the window, [32..63] first_du - U0, [64..95] entries
         const uint32_t U0 = wg.first_mcu * dus;
         const uint32_t g0 = mark.ent_off / PJD_GROUP;          // the range starts in this group of lane q
         const uint32_t gcap = B.lane_cap / PJD_GROUP;
