@@ -326,7 +326,6 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.coef, P.dense_du * 64, tot));
     TRY_RC(dev_alloc(ctx, b->dev.ent, (size_t)P.n_ent, tot));
     TRY_RC(dev_alloc(ctx, b->dev.lane_info, P.subs.size(), tot));
-    TRY_RC(dev_alloc(ctx, b->dev.ghead, P.subs.size() * (size_t)(P.lane_cap / PJD_GROUP), tot));
     TRY_RC(dev_alloc(ctx, b->dev.lane_dc, P.subs.size(), tot));
     TRY_RC(dev_alloc(ctx, b->dev.dc_blk, (size_t)P.n_dcblk * 8, tot));
     TRY_RC(dev_alloc(ctx, b->dev.marks, P.iwgs.size(), tot));
@@ -719,9 +718,6 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
                 std::sort(cl.begin(), cl.end());
                 std::fprintf(stderr, "[pjd waves] shader clock while the waves ran: median %.2f GHz (min %.2f, max %.2f)\n", cl[nw / 2] / 160.0, cl.front() / 160.0, cl.back() / 160.0);
             }
-            std::fprintf(stderr, "[pjd back end] parser chunk iterations %llu for %llu entries in %zu workgroups (%.2f per workgroup; %.0f %% of the %d-entry slots used)\n",
-                         (unsigned long long)b->h_stats[14], (unsigned long long)b->h_stats[PJD_STAT_ENTRIES], P.iwgs.size(), (double)b->h_stats[14] / (double)(P.iwgs.size() ? P.iwgs.size() : 1),
-                         100.0 * (double)b->h_stats[PJD_STAT_ENTRIES] / ((double)(b->h_stats[14] ? b->h_stats[14] : 1) * 1024.0), 1024);
             std::fprintf(stderr, "[pjd waves] n %zu | mean(us): start %.1f passA %.1f rounds %.1f stitch %.1f scan %.1f write+verify %.1f | max(us): %.1f %.1f %.1f %.1f %.1f %.1f\n",
                          nw, sum[0] / n / 100, sum[1] / n / 100, sum[2] / n / 100, sum[3] / n / 100, sum[4] / n / 100, sum[5] / n / 100,
                          mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0, mx[4] / 100.0, mx[5] / 100.0);

@@ -70,13 +70,16 @@
 // Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
 // the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
 #define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
-// Entries (2 bytes, one per decoded symbol) a lane may emit into its own region.  Every symbol consumes at least `min_bits` bits
+// Slots (2 bytes each) of a lane's region.  Every symbol consumes at least `min_bits` bits
 // of stream -- the smallest (code length + value bits) over the Huffman tables the batch uses, computed by the planner; 1 if a
 // table has a 1-bit code for a size-0 symbol -- so a lane of `sub_bytes` bytes emits at most 8 * sub_bytes / min_bits entries,
-// plus the symbol that may have started before it and a flush unit of slack.  (Annex-K tables: 2 bits; optimised tables of very
+// plus the symbol that may have started before it and some slack.  (Annex-K tables: 2 bits; optimised tables of very
 // low qualities reach 1.5 bits per symbol on average -- a 1-bit EOB after a 2-bit DC code -- but no single symbol below 1.)
-// The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.  A multiple of 16 entries: regions stay 32-byte aligned.
-#define PJD_LANE_CAP(sub_bytes, min_bits)   ((((8u * (sub_bytes) + (min_bits) - 1) / (min_bits) + 64u) + 15u) & ~15u)
+// A region is a sequence of 32-byte GROUPS: two slots of head + PJD_GROUP_ENTRIES (14) entries (below), so the capacity in slots is
+// 16 / 14 of the entry bound, a whole number of groups.  The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.
+#define PJD_GROUP          16       // slots per group = entries the write pass stages between two flushes
+#define PJD_GROUP_ENTRIES  (PJD_GROUP - 2)
+#define PJD_LANE_CAP(sub_bytes, min_bits)   ((((8u * (sub_bytes) + (min_bits) - 1) / (min_bits) + 64u + PJD_GROUP_ENTRIES - 1) / PJD_GROUP_ENTRIES + 1u) * PJD_GROUP)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
 // The write pass turns every decoded Huffman symbol into exactly one 16-bit entry:
@@ -87,6 +90,12 @@
 // A unit is [DC][AC ...] up to and including the first entry with bit 11 set; the slot of an AC entry is the
 // running sum of (run + 1) over the unit.  A size-0 symbol stores an explicit 0 (reference
 // src/jpeg_scanner.cpp:516-517), which matters at slot 52 only (zigzag quirk).
+// Entries are kept in GROUPS of 16 slots = 32 bytes, the unit the write pass flushes: slots 0..1 hold the group's HEAD, one 32-bit
+// word `[units completed in this lane before the group's first entry : 24][zigzag slot that entry fills from : 8]` (slot 0: the entry
+// is a unit's DC difference; else the AC coefficient lands on slot + run), slots 2..15 hold 14 entries.  With the head a back-end
+// thread parses its group without looking at anything before it (pjd_k_idct_colour_lanes); the head travels in the same 32-byte
+// store as its entries (kept in an array of its own it cost 64 bytes of HBM traffic per 4-byte word, profiles/r03_experiments.md).
+// Positions in a lane's region (PjdDevLaneInfo::n_ent, PjdDevMark::ent_off) count SLOTS, heads included.
 #define PJD_ENT_LAST       0x0800u
 
 // ---- image flags (device side) -----------------------------------------------------
@@ -259,18 +268,13 @@ struct PjdDevIdctWg {                  // one IDCT/colour workgroup = one coeffi
 
 // what a Huffman lane leaves behind for the back end (written at the end of its write pass)
 struct PjdDevLaneInfo {
-    uint32_t n_ent;                    // entries in the lane's region
+    uint32_t n_ent;                    // slots used in the lane's region (group heads included)
     uint32_t first_du;                 // bits 27..0: image-relative index of the data unit the lane's first entry belongs to (a unit may span lanes);
                                        // bit 31: the lane starts a restart segment (DC predictors are zero there)
     uint16_t dc_sum[3];                // sum of the DC differences decoded in this lane, per component (mod 2^16)
     uint16_t pad_;
 };
 #define PJD_LANE_SEG_FIRST 0x80000000u
-// Group heads (PjdDevBatch::ghead): entries are parsed in GROUPS of PJD_GROUP consecutive entries of one lane, one back-end thread each
-// (pjd_k_idct_colour_lanes).  To start in the middle of a lane the thread needs where the group's first entry stands: the write pass
-// leaves one word per group, `[units completed in this lane before the entry : 24][zigzag slot the entry fills from : 8]` (slot 0: the
-// entry is a unit's DC difference; else the AC coefficient of the entry lands on slot + run).  Lane q's heads: ghead[q * (lane_cap / PJD_GROUP) + g].
-#define PJD_GROUP 16
 
 // DC predictors at the start of a lane, from the scan over PjdDevLaneInfo::dc_sum (pjd_k_lane_dc_*)
 struct PjdDevLaneDc {

@@ -584,9 +584,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 // ---------------------------------------------------------------------------------------------
 #define PJD_PARSE_PER_THREAD 4
 #define PJD_PARSE_CHUNK (PJD_IDCT_THREADS * PJD_PARSE_PER_THREAD)
-#ifndef PJD_PARSE_GROUPS
-#define PJD_PARSE_GROUPS 1            // 1: one thread per group of 16 entries (group heads from the write pass); 0: the round-2 parser (scans over 1024-entry chunks)
-#endif
 
 // Inclusive scans over the 64 lanes of a wave with DPP moves (VALU only, no LDS round trips): shifts inside each row of
 // 16 lanes, then the last lane of a row broadcast into the following rows.  Values are unsigned; 0 is the identity of both.
@@ -669,11 +666,10 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 #pragma unroll
         for (int c = 0; c < 3; c++) pred0[c] = (uint32_t)ld.dc_in[c] + (ld.abs ? 0u : (uint32_t)carry[c]) + mark.acc[c];
     }
-#if PJD_PARSE_GROUPS
     __syncthreads();
-    // ---- parse: entries -> tile, one thread per GROUP of PJD_GROUP consecutive entries of a lane.  The write pass left with every
-    // group where its first entry stands (PjdDevBatch::ghead: units completed in the lane before it, slot it fills from) and with
-    // every lane the unit its first entry belongs to (PjdDevLaneInfo::first_du), so a thread walks its 16 entries on its own: a DC
+    // ---- parse: entries -> tile, one thread per GROUP (32 bytes: a head and 14 entries, pjd_internal.h) of a lane.  The write pass
+    // left in every head where the group's first entry stands (units completed in the lane before it, slot it fills from) and with
+    // every lane the unit its first entry belongs to (PjdDevLaneInfo::first_du), so a thread walks its 14 entries on its own: a DC
     // entry opens a unit, an AC entry lands on slot + run, the LAST bit closes the unit -- no scans over entries, no barriers
     // between chunks (round 2: two wave scans and two barriers per 1024 entries, ~70 instructions per entry against ~25 here).
     // Lanes are taken in windows of 32 (a range of 96 units spans 3-4 lanes of a dense picture, ~20 of 128 bytes); the window's
@@ -682,7 +678,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         // ltab: [0..31] groups before lane i of the window, [32..63] first_du - U0, [64..95] entries
         const uint32_t U0 = wg.first_mcu * dus;
         const uint32_t g0 = mark.ent_off / PJD_GROUP;          // the range starts in this group of lane q
-        const uint32_t gcap = B.lane_cap / PJD_GROUP;
         // where the NEXT range starts (its mark) bounds this one; usable when every unit of this range was decoded
         uint32_t q_end = 0xffffffffu, g_end = 0;
         if (n_valid == n_du && blockIdx.x + 1 < im.iwg_base + im.n_iwg) {
@@ -723,14 +718,14 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                 const uint32_t g = w - ltab[li_] + (ql == q ? g0 : 0u);
                 const uint32_t ne = ltab[64 + li_];
                 const uint32_t cnt = ne - g * PJD_GROUP < PJD_GROUP ? ne - g * PJD_GROUP : PJD_GROUP;
-                const uint32_t head = B.ghead[(size_t)ql * gcap + g];
-                uint32_t u = ltab[32 + li_] + (head >> 8);                  // unit of the group's first entry, relative to the range
-                uint32_t slot = head & 63u;                                 // 0: that entry is a DC difference
                 const uint4 *src = reinterpret_cast<const uint4 *>(B.ent + (size_t)ql * B.lane_cap + (size_t)g * PJD_GROUP);
-                const uint4 r0 = src[0], r1 = src[1];                       // 32 bytes, 32-byte aligned (lane_cap and PJD_GROUP are multiples of 16 entries)
+                const uint4 r0 = src[0], r1 = src[1];                       // the group: 32 bytes, 32-byte aligned
                 const uint32_t wds[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                const uint32_t head = wds[0];
+                uint32_t u = ltab[32 + li_] + (head >> 8);                  // unit of the group's first entry, relative to the range ("negative" before it)
+                uint32_t slot = head & 63u;                                 // 0: that entry is a DC difference
 #pragma unroll
-                for (int k = 0; k < PJD_GROUP; k++) {
+                for (int k = 2; k < PJD_GROUP; k++) {
                     const uint32_t e = (k & 1) ? wds[k >> 1] >> 16 : wds[k >> 1] & 0xffffu;
                     if ((uint32_t)k >= cnt) { }
                     else if (slot == 0) {                                        // DC difference: 12-bit two's complement
@@ -754,114 +749,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             if (!again) break;
         }
     }
-#else
-    uint32_t n_ent = B.lane_info[q].n_ent;
-    __syncthreads();
-
-    // ---- parse: entries -> tile.  Per entry: U = units completed before it, A = (run + 1) summed over the entries
-    // before it (a DC entry counts 1), M = A at the start of its unit; zigzag slot = A - M + run.  U and A come from one
-    // additive scan, M from a max scan (A never decreases).
-    uint32_t run_units = 0, run_tail = 0;                       // over the chunks so far (uniform): units done, A - M at the chunk start
-    uint32_t it = 0;
-    for (; run_units < n_valid; ) {
-        if (n >= n_ent) {                                       // next lane of the image
-            q++; n = 0;
-            if (q >= lane_end) break;
-            n_ent = B.lane_info[q].n_ent;
-            continue;
-        }
-        const uint32_t cnt = n_ent - n < PJD_PARSE_CHUNK ? n_ent - n : PJD_PARSE_CHUNK;
-        const uint16_t *src = B.ent + (size_t)q * B.lane_cap + n;
-        const uint32_t i0 = tid * PJD_PARSE_PER_THREAD;
-        uint32_t e[PJD_PARSE_PER_THREAD], prev = 0;
-        {
-            struct __attribute__((packed, aligned(2))) E4 { uint32_t a, b; };
-            E4 raw = {0, 0};
-            if (i0 < cnt) raw = *reinterpret_cast<const E4 *>(src + i0);     // reads inside the lane's region (cap is a multiple of 4 past any n_ent)
-            e[0] = raw.a & 0xffffu; e[1] = raw.a >> 16; e[2] = raw.b & 0xffffu; e[3] = raw.b >> 16;
-            if (i0 > 0 && i0 < cnt) prev = src[i0 - 1];
-        }
-        // the entry before a thread's first one tells whether that one opens a unit; at the chunk start the running tail does
-        bool dc_next = i0 == 0 ? run_tail == 0 : (prev & PJD_ENT_LAST) != 0;
-        bool isdc[PJD_PARSE_PER_THREAD];
-        uint32_t adv[PJD_PARSE_PER_THREAD], last[PJD_PARSE_PER_THREAD];
-        uint32_t sum = 0;                                       // units << 16 | adv, over this thread's entries
-#pragma unroll
-        for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
-            const bool valid = i0 + k < cnt;
-            isdc[k] = dc_next;
-            last[k] = valid ? (e[k] >> 11) & 1u : 0u;
-            adv[k] = valid ? (isdc[k] ? 1u : (e[k] >> 12) + 1u) : 0u;
-            dc_next = last[k] != 0;
-            sum += adv[k] + (last[k] << 16);
-        }
-        uint32_t inc = sum;
-        PJD_WAVE_SCAN(pjd_op_add, inc);
-        if (lane == 63) wagg[it & 1][wv][0] = inc;
-        uint32_t exc = pjd_wave_prev(inc);                      // everything before this thread, inside the wave
-        __syncthreads();
-        uint32_t before = run_tail, total = run_tail;           // adds of the waves before this one / of the whole chunk
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t a = wagg[it & 1][k][0];
-            if (k < wv) before += a;
-            total += a;
-        }
-        exc += before;                                          // units completed in this chunk before the thread << 16 | A
-        // unit-start marks: A just after every completed unit, max-scanned
-        uint32_t mloc = 0, a_run = exc & 0xffffu, mk[PJD_PARSE_PER_THREAD];
-#pragma unroll
-        for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
-            mk[k] = mloc;                                       // mark from this thread's own earlier entries (0: none)
-            a_run += adv[k];
-            if (last[k]) mloc = a_run;
-        }
-        uint32_t minc = mloc;
-        PJD_WAVE_SCAN(pjd_op_max, minc);
-        if (lane == 63) wagg[it & 1][wv][1] = minc;
-        uint32_t mexc = pjd_wave_prev(minc);
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t a = wagg[it & 1][k][1];
-            if (k < wv) mexc = pjd_op_max(mexc, a);
-        }
-        // scatter: de-zigzag + dequantise (reference src/jpeg_scanner.cpp:517, src/decoder_dpu.c:169-172)
-        uint32_t u = run_units + (exc >> 16), a_pos = exc & 0xffffu;
-#pragma unroll
-        for (int k = 0; k < PJD_PARSE_PER_THREAD; k++) {
-            if (i0 + k < cnt && u < n_valid) {
-                if (isdc[k]) dcraw[u] = (int)(((e[k] & 0x7ffu) | ((e[k] >> 1) & 0x800u)) << 20) >> 20;
-                else {
-                    const int val = (int)(e[k] << 21) >> 21;
-                    const uint32_t m = mk[k] > mexc ? mk[k] : mexc;
-                    const uint32_t slot = a_pos - m + (e[k] >> 12);
-                    const bool term = (e[k] & 0xf7ffu) == 0;                     // EOB: completes the unit, stores nothing
-                    if (!term && slot < 64) {
-                        const uint32_t comp = comp_of[u];
-                        if (slot == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
-                        else { const uint32_t qe = qz[comp][slot]; tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu); }
-                    }
-                }
-            }
-            a_pos += adv[k];
-            u += last[k];
-        }
-        // carry into the next chunk: units done; A - M at the chunk end (all threads compute the same)
-        {
-            uint32_t mall = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) mall = pjd_op_max(mall, wagg[it & 1][k][1]);
-            run_units += total >> 16;
-            run_tail = (total & 0xffffu) - mall;
-        }
-        n += cnt;
-        it++;                                                   // the other copy of wagg next time
-    }
-    if (B.dbg && tid == 0) atomicAdd(B.stats + 14, (unsigned long long)(it));   // PJD_DEBUG_STATS: chunk iterations of the parser
-    __syncthreads();
-
-#endif
 #if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 1      // timing experiments only (tools/r2_occ.sh): pictures are wrong
     if (tile[0][0] == 12345) B.out[0] = 1;
     return;

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64) void pjd_k_coefdump_lanes(PjdDevBatch B, uint32
             n_ent = B.lane_info[q].n_ent;
             continue;
         }
+        if ((n & (PJD_GROUP - 1)) < 2) { n = (n & ~(uint32_t)(PJD_GROUP - 1)) + 2; continue; }      // a group's head (pjd_internal.h)
         const uint32_t e = B.ent[(size_t)q * B.lane_cap + n];
         n++;
         if (!in_unit) {                      // DC entry (layout: pjd_internal.h): 12-bit two's complement difference

@@ -48,7 +48,7 @@
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
 static_assert(PJD_LUT_BITS + PJD_L2_BITS == 16 && PJD_L1_BYTES == (4 << PJD_LUT_BITS), "two-level table geometry");
 static_assert(PJD_HUFF_LANES == 64, "one wave per 64 lanes");
-static_assert(PJD_STAGE_ENTRIES == PJD_GROUP, "a group head is written with every flush of the staging buffer");
+static_assert(PJD_STAGE_ENTRIES == PJD_GROUP, "a group (head + 14 entries) is what one flush of the staging buffer writes");
 
 #define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSYM)    // no code: consume 16 bits (as the reference's get_next_symbol)
 
@@ -498,7 +498,7 @@ struct OutCtx {
     uint16_t *region;      // the lane's entry region (HBM)
     uint32_t *stage;       // LDS: [16 rows][64 lanes] dwords at this lane's column: two entries per dword
     uint32_t cap;          // entries the region holds
-    uint32_t n;            // entries emitted
+    uint32_t n;            // slots used so far (pjd_internal.h: groups of a 2-slot head + 14 entries); even whenever a step begins
     uint32_t dcA, dcB;     // DC differences summed so far, each mod 2^16: Y (low) Cb (high) | Cr (low)
     uint32_t left;         // data units to complete before the next unit that starts an IDCT workgroup's range
     uint32_t ru;           // data units per IDCT workgroup
@@ -506,7 +506,6 @@ struct OutCtx {
     uint32_t mark_next;    // index of the next mark this lane would write
     uint32_t lane_q;
     uint32_t overflow;
-    uint32_t *ghead;       // this lane's group heads (pjd_internal.h)
     uint32_t D_in;         // the lane's first data unit
 };
 
@@ -598,7 +597,8 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
         const uint4 cur = lds_u32x4(P.self(P.dus1 - c));
         S.x = cur.x; S.ra = cur.y; S.mA = cur.z; S.mB = cur.w;
     }
-    O.ghead[0] = z;                                                          // group 0: no unit completed yet, the first entry fills from slot z
+    O.stage[0] = z;                                                          // head of group 0: no unit completed yet, the first entry fills from slot z
+    O.n = 2;
     for (;;) {
         if (S.p >= end_bit || D >= D_end) break;
         const uint32_t e0 = write_step(P.lbase, w, S, D, O);
@@ -610,7 +610,8 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
         if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {
             stage_flush(O, O.n - PJD_STAGE_ENTRIES);
             if (O.n + PJD_STAGE_ENTRIES > O.cap) { O.overflow = 1; break; }
-            O.ghead[O.n / PJD_GROUP] = ((D - O.D_in) << 8) | (63u - (uint32_t)S.zb);           // where the next group's first entry stands
+            O.stage[0] = ((D - O.D_in) << 8) | (63u - (uint32_t)S.zb);      // head of the next group: where its first entry stands
+            O.n += 2;
         }
     }
     if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
@@ -637,7 +638,7 @@ struct Careful {
 };
 
 __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col, uint32_t p, uint32_t c, uint32_t z,
-                                          uint32_t end_bit, uint32_t eof_rel, uint32_t D, uint32_t D_end, uint16_t *region, uint32_t cap, uint32_t *ghead, Careful &R)
+                                          uint32_t end_bit, uint32_t eof_rel, uint32_t D, uint32_t D_end, uint16_t *region, uint32_t cap, Careful &R)
 {
     const uint32_t D_in = D;
     BitWin w;
@@ -648,7 +649,11 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
     const bool at_end = eof_rel != 0xffffffffu;
     while (D < D_end && (p < end_bit || at_end)) {
         const bool is_dc = zb == 63;
-        if ((R.n & (PJD_GROUP - 1)) == 0 && R.n < cap) ghead[R.n / PJD_GROUP] = ((D - D_in) << 8) | (63u - (uint32_t)zb);      // group head (pjd_internal.h)
+        if ((R.n & (PJD_GROUP - 1)) == 0 && R.n + 2 <= cap) {                    // a group begins: its head (pjd_internal.h), two slots
+            const uint32_t h = ((D - D_in) << 8) | (63u - (uint32_t)zb);
+            region[R.n] = (uint16_t)h; region[R.n + 1] = (uint16_t)(h >> 16);
+            R.n += 2;
+        }
         const uint32_t pk = w.peek();
         const uint4 nx = lds_u32x4(cur.y);
         const uint32_t e = lut_lookup(P.lbase, is_dc ? (cur.x & 0xffffu) : (cur.x >> 16), pk);
@@ -1083,7 +1088,6 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
             O.ru = im.idct_mcus * dus;
             O.marks = B.marks + im.iwg_base;
             O.lane_q = g.q;
-            O.ghead = B.ghead + (size_t)g.q * (B.lane_cap / PJD_GROUP);
             O.D_in = D_in;
             li.first_du |= D_in;
             {   // the next data unit that STARTS in this lane and opens an IDCT workgroup's range
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 // an entropy-coding error of the TRUE decode (this lane started from the true state): find it exactly, keep what
                 // precedes it, report it by position -- the picture's verdict takes the first one (pjd_k_image_verdict)
                 Careful R;
-                careful_span(P, g.words, g.col, p0, c0, z0, g.end_bit, eof_lane ? g.seg_end_bit : 0xffffffffu, D_in, D_end, O.region, O.cap, O.ghead, R);
+                careful_span(P, g.words, g.col, p0, c0, z0, g.end_bit, eof_lane ? g.seg_end_bit : 0xffffffffu, D_in, D_end, O.region, O.cap, R);
                 if (R.cls) {
                     li.n_ent = R.n;
                     li.dc_sum[0] = (uint16_t)R.dcA; li.dc_sum[1] = (uint16_t)(R.dcA >> 16); li.dc_sum[2] = (uint16_t)R.dcB;
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     // flagged lane; conditions that concern the whole wave flag every lane, i.e. the wave's first).  Whether that sends the picture
     // to the exact kernel is decided per picture once all its waves have reported (pjd_k_image_verdict): what lies behind the
     // picture's first entropy-coding error is never decoded by the reference and does not count.
-    uint32_t wflag = flag, went = g.valid ? li.n_ent : 0, wpos = (flag && g.valid) ? g.base_bit : 0xffffffffu;
+    uint32_t wflag = flag, went = g.valid ? li.n_ent - 2u * ((li.n_ent + PJD_GROUP - 1) / PJD_GROUP) : 0, wpos = (flag && g.valid) ? g.base_bit : 0xffffffffu;
     for (int off = 1; off < 64; off <<= 1) {
         wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off);
         const uint32_t o = __shfl_xor(wpos, off);

@@ -23,7 +23,6 @@ struct PjdDevBatch {
     int16_t *coef;                       // DENSE scratch (exact-kernel path): dense_du * 64 int16, zigzag-slot order
     uint16_t *ent;                       // lane streams: lane q owns entries [q * lane_cap, (q + 1) * lane_cap)
     PjdDevLaneInfo *lane_info;           // per lane
-    uint32_t *ghead;                     // group heads of the lane streams (pjd_internal.h): [lane][lane_cap / PJD_GROUP]
     PjdDevLaneDc *lane_dc;               // per lane
     uint16_t *dc_blk;                    // per DC scan block: aggregate {Y, Cb, Cr, has_head}, then carry-in {Y, Cb, Cr, -}
     PjdDevMark *marks;                   // per IDCT workgroup of the parallel path
