@@ -577,13 +577,11 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour(PjdDevBatc
 
 // ---------------------------------------------------------------------------------------------
 // Lane-stream front end: the parallel entropy decoder leaves one 16-bit entry per symbol in per-lane
-// regions (layout: pjd_internal.h) and, for the first data unit of every IDCT workgroup, a mark
-// (lane, entry offset, DC sums so far).  The workgroup walks the entries from its mark, 1024 at a time:
-// unit index = number of "unit complete" bits before an entry, zigzag slot = sum of (run + 1) over the
-// unit so far -- two scans over the chunk -- then de-zigzags and dequantises into the LDS tile.
+// regions, in 32-byte groups of a head and 14 entries (layout: pjd_internal.h), the data unit every lane starts in, and,
+// for the first data unit of every IDCT workgroup, a mark (lane, slot, DC sums so far).  The workgroup finds the lanes its
+// range of units lies in, and one thread per group walks the group from its head: unit index and zigzag slot of every
+// entry follow from the head and the entries before it in the group; it de-zigzags and dequantises into the LDS tile.
 // ---------------------------------------------------------------------------------------------
-#define PJD_PARSE_PER_THREAD 4
-#define PJD_PARSE_CHUNK (PJD_IDCT_THREADS * PJD_PARSE_PER_THREAD)
 
 // Inclusive scans over the 64 lanes of a wave with DPP moves (VALU only, no LDS round trips): shifts inside each row of
 // 16 lanes, then the last lane of a row broadcast into the following rows.  Values are unsigned; 0 is the identity of both.
@@ -621,7 +619,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     __shared__ int dcraw[PJD_IDCT_MAX_DU];    // DC difference of every unit
     __shared__ uint32_t s52[PJD_IDCT_MAX_DU]; // entry at slot 52, if the unit has one
     __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
-    __shared__ uint32_t wagg[2][4][2];        // per chunk parity, per wave: (units completed << 16 | sum of run+1), max unit-start mark
+    __shared__ uint32_t wagg[2];              // group parser: groups in the lane window; whether the lane behind the window may belong to the range
     __shared__ uint32_t ltab[96];             // group parser: the window's lane table
 
 #if PJD_IDCT_PRIO
@@ -705,11 +703,11 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 #pragma unroll
                 for (int off = 1; off < 32; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if ((int)tid >= off) inc += t; }
                 ltab[tid] = inc - ng; ltab[32 + tid] = fd; ltab[64 + tid] = ne;
-                if (tid == 31) { wagg[0][0][0] = inc; wagg[0][0][1] = more ? 1u : 0u; }   // groups in the window; the lane behind it may belong to the range too
+                if (tid == 31) { wagg[0] = inc; wagg[1] = more ? 1u : 0u; }   // groups in the window; the lane behind it may belong to the range too
             }
             __syncthreads();
-            const uint32_t G = wagg[0][0][0];
-            const bool again = wagg[0][0][1] != 0 && qw + 32 < lane_end;
+            const uint32_t G = wagg[0];
+            const bool again = wagg[1] != 0 && qw + 32 < lane_end;
             for (uint32_t w = tid; w < G; w += PJD_IDCT_THREADS) {
                 uint32_t li_ = 0;                                           // last lane of the window whose groups start at or before w
 #pragma unroll
