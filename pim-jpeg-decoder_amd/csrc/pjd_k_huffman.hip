@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
 // One block per Huffman wave: the wave's 64 lane streams as big-endian words, transposed.
 // A lane's 128-byte source lines are re-read from L1 for 32 consecutive rows; the rows are written whole.
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
+#ifndef PJD_WORDS_X4
+#define PJD_WORDS_X4 1
+#endif
+
+struct __attribute__((packed)) UnalignedU32x4 { uint32_t v[4]; };
 
 __global__ __launch_bounds__(256) void pjd_k_lane_words(PjdDevBatch B)
 {
@@ -134,15 +139,29 @@ __global__ __launch_bounds__(256) void pjd_k_lane_words(PjdDevBatch B)
     const PjdDevHuffWave hw = B.hwaves[wv];
     const PjdDevImage &im = B.images[hw.image];
     const uint32_t l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
-    const uint32_t rows = PJD_WORD_ROWS(im.sub_bytes);          // of this image: at most B.word_rows, the stride between waves
+    const uint32_t rows = PJD_WORD_ROWS(im.sub_bytes);          // of this image: at most B.word_rows, the stride between waves; a multiple of 4
     uint32_t *dst = B.words + (size_t)wv * B.word_rows * 64;
     const bool valid = l < hw.n_lanes;
     const uint8_t *src = B.ecs + im.ecs_off + (valid ? B.lanes[hw.first_lane + l].byte_start : 0u);
+#if PJD_WORDS_X4
+    // 16 bytes of the lane's stream per load (four rows), four groups of rows in flight per thread
+    for (uint32_t k = 4 * k0; k < rows; k += 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (valid) {
+            const UnalignedU32x4 v = *reinterpret_cast<const UnalignedU32x4 *>(src + 4 * k);
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = __builtin_bswap32(v.v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[(k + j) * 64 + l] = w[j];
+    }
+#else
     for (uint32_t k = k0; k < rows; k += 4) {
         uint32_t w = 0;
         if (valid) w = __builtin_bswap32(reinterpret_cast<const UnalignedU32 *>(src + 4 * k)->v);
         dst[k * 64 + l] = w;
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
