@@ -446,7 +446,10 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
         const uint32_t rn = WALK_NEXT(r), xa = WALK_TABS(r), xb = WALK_TABS(rn);
         // the symbol at every position under the DC and AC tables of the current unit and of the unit after it: four reads in flight
         const uint32_t i4 = 4u * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS);
-        const uint32_t e0 = lds_u32((xa & 0xffffu) + i4), e1 = lds_u32((xa >> 16) + i4), e2 = lds_u32((xb & 0xffffu) + i4), e3 = lds_u32((xb >> 16) + i4);   // (the symbol: low half)
+        // (the DC table of the current unit only if the walk stands at its DC symbol; of the entries the low half: the symbol)
+        const uint32_t e1 = lds_u32((xa >> 16) + i4), e2 = lds_u32((xb & 0xffffu) + i4), e3 = lds_u32((xb >> 16) + i4);
+        uint32_t e0 = e1;
+        if (zb == 63) e0 = lds_u32((xa & 0xffffu) + i4);
         // A position whose code is longer than 9 bits (a pointer entry) gets the mark WALK_PTR instead of its delta: the chase stops
         // there and the ONE second-level entry it needs is fetched then (long codes are rare on the path; they are not among 256 lookups).
 #define WALK_PTR 0x40000000u
