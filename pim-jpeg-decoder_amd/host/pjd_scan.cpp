@@ -40,7 +40,7 @@ struct Bytes {
         if (bad || pos >= n) { bad = true; return -1; }
         return p[pos++];
     }
-    uint32_t be16() { int hi = get(), lo = get(); return (uint32_t)((hi << 8) + lo); }
+    uint32_t be16() { int hi = get(), lo = get(); return (uint32_t)(hi * 256 + lo); }     // (past the end: -1 * 256 + -1, as the reference's (get() << 8) + get() yields)
 };
 
 }  // namespace
