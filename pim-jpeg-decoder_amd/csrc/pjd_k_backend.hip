@@ -616,7 +616,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
     __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
-    __shared__ int dcraw[PJD_IDCT_MAX_DU];    // DC difference of every unit
     __shared__ uint32_t s52[PJD_IDCT_MAX_DU]; // entry at slot 52, if the unit has one
     __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
     __shared__ uint32_t wagg[2];              // group parser: groups in the lane window; whether the lane behind the window may belong to the range
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     for (uint32_t i = tid; i < n_du * (TILE_STRIDE * 2 / 16); i += PJD_IDCT_THREADS)
         reinterpret_cast<uint4 *>(&tile[0][0])[i] = make_uint4(0, 0, 0, 0);
     if (tid < PJD_IDCT_MAX_DU) {
-        s52[tid] = 0; dcraw[tid] = 0;
+        s52[tid] = 0;
         const uint32_t kk = tid % dus;                          // the range starts on an MCU boundary
         comp_of[tid] = (uint8_t)(kk < nl ? 0 : kk - nl + 1);
     }
@@ -725,21 +724,22 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 #pragma unroll
                 for (int k = 2; k < PJD_GROUP; k++) {
                     const uint32_t e = (k & 1) ? wds[k >> 1] >> 16 : wds[k >> 1] & 0xffffu;
-                    if ((uint32_t)k >= cnt) { }
-                    else if (slot == 0) {                                        // DC difference: 12-bit two's complement
-                        if (u < n_valid) dcraw[u] = (int)(((e & 0x7ffu) | ((e >> 1) & 0x800u)) << 20) >> 20;
-                        slot = 1;
-                    } else {
-                        const uint32_t s_ = slot + (e >> 12);
-                        const bool term = (e & 0xf7ffu) == 0;                    // EOB: completes the unit, stores nothing
-                        if (!term && s_ < 64 && u < n_valid) {
-                            const int val = (int)(e << 21) >> 21;
-                            const uint32_t comp = comp_of[u];
-                            if (s_ == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
-                            else { const uint32_t qe = qz[comp][s_]; tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu); }
+                    // ONE path for both kinds of entry (the lanes of a wave stand at DC and AC entries at once): a DC difference (slot == 0) is
+                    // "a coefficient for position 0 with quantiser 1" -- its raw 12-bit value waits in the tile for the DC stage
+                    const bool dc = slot == 0;
+                    const uint32_t s_ = dc ? 0u : slot + (e >> 12);
+                    const bool term = !dc && (e & 0xf7ffu) == 0;                 // EOB: completes the unit, stores nothing
+                    if ((uint32_t)k < cnt && !term && s_ < 64 && u < n_valid) {
+                        const int val = dc ? (int)(((e & 0x7ffu) | ((e >> 1) & 0x800u)) << 20) >> 20 : (int)(e << 21) >> 21;
+                        if (s_ == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
+                        else {
+                            const uint32_t qe = dc ? 1u : qz[comp_of[u]][s_];
+                            tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
                         }
+                    }
+                    if ((uint32_t)k < cnt) {
                         slot = s_ + 1;
-                        if (e & PJD_ENT_LAST) { u++; slot = 0; }
+                        if (!dc && (e & PJD_ENT_LAST)) { u++; slot = 0; }
                     }
                 }
             }
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             const uint32_t u = base + lane;
             const bool on = u < n_valid;                        // an undecoded unit keeps DC 0: it is never predicted
             const uint32_t d = d0 + u, m = d / dus, kk = d - m * dus, comp = kk < nl ? 0 : kk - nl + 1;
-            const uint32_t dv = on ? (uint32_t)dcraw[on ? u : 0] & 0xffffu : 0u;
+            const uint32_t dv = on ? (uint32_t)(uint16_t)tile[on ? u : 0][0] : 0u;     // the unit's DC difference as the parser left it (zero if the unit has none)
             const bool head = on && kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0));
             // sums since the group start (inclusive), Y | Cb, Cr packed; then the same sums at the last head at or before the unit
             uint32_t vy = comp == 0 ? dv : 0u, vc = comp == 1 ? dv : (comp == 2 ? dv << 16 : 0u);
