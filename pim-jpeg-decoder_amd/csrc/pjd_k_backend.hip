@@ -664,6 +664,10 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         for (int c = 0; c < 3; c++) pred0[c] = (uint32_t)ld.dc_in[c] + (ld.abs ? 0u : (uint32_t)carry[c]) + mark.acc[c];
     }
     __syncthreads();
+#if defined(PJD_IDCT_STOP_AFTER) && PJD_IDCT_STOP_AFTER == 0      // timing experiments only: set-up alone
+    if (tile[0][0] == 12345) B.out[0] = 1;
+    return;
+#endif
     // ---- parse: entries -> tile, one thread per GROUP (32 bytes: a head and 14 entries, pjd_internal.h) of a lane.  The write pass
     // left in every head where the group's first entry stands (units completed in the lane before it, slot it fills from) and with
     // every lane the unit its first entry belongs to (PjdDevLaneInfo::first_du), so a thread walks its 14 entries on its own: a DC
