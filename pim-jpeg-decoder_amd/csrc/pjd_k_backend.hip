@@ -616,7 +616,6 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
     __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
-    __shared__ uint32_t s52[PJD_IDCT_MAX_DU]; // entry at slot 52, if the unit has one
     __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
     __shared__ uint32_t wagg[2];              // group parser: groups in the lane window; whether the lane behind the window may belong to the range
     __shared__ uint32_t ltab[96];             // group parser: the window's lane table
@@ -633,15 +632,21 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     const uint32_t RI = im.restart_interval;
 
     const bool quirk = !(im.flags & PJD_IF_STANDARD_ZIGZAG);    // the reference's zigzag_map[48] = 38 (default)
+    // The reference's zigzag quirk: slots 48 AND 52 land on natural position 38, and the later one -- slot 52, even an explicit zero --
+    // wins.  Entries of one unit may be parsed by two threads, so slot 52 is parked in the first padding cell of the unit's tile row
+    // (position 64, raw value: quantiser 1; the cell starts as PJD_COEF_SENTINEL = "no slot 52 in this unit") and moved over
+    // position 38 when the rows are done.
     if (tid < 192) {
         const uint32_t nat = (!quirk && (tid & 63) == 48) ? 58u : c_zz[tid & 63];
-        qz[tid >> 6][tid & 63] = (uint32_t)B.qtab[(size_t)wg.image * 192 + (tid & ~63u) + nat] | (nat << 16);
+        uint32_t v = (uint32_t)B.qtab[(size_t)wg.image * 192 + (tid & ~63u) + nat] | (nat << 16);
+        if (quirk && (tid & 63) == 52) v = 1u | (64u << 16);
+        qz[tid >> 6][tid & 63] = v;
     }
-    // unvisited positions are zero (the reference's buffers start zeroed)
+    // unvisited positions are zero (the reference's buffers start zeroed); a row is 9 x 16 bytes, the last of them padding
+    static_assert(TILE_STRIDE == 72, "the padding cell of a tile row is element 64");
     for (uint32_t i = tid; i < n_du * (TILE_STRIDE * 2 / 16); i += PJD_IDCT_THREADS)
-        reinterpret_cast<uint4 *>(&tile[0][0])[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4 *>(&tile[0][0])[i] = make_uint4(i % 9u == 8u ? (uint32_t)(uint16_t)PJD_COEF_SENTINEL : 0u, 0, 0, 0);
     if (tid < PJD_IDCT_MAX_DU) {
-        s52[tid] = 0;
         const uint32_t kk = tid % dus;                          // the range starts on an MCU boundary
         comp_of[tid] = (uint8_t)(kk < nl ? 0 : kk - nl + 1);
     }
@@ -735,11 +740,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                     const bool term = !dc && (e & 0xf7ffu) == 0;                 // EOB: completes the unit, stores nothing
                     if ((uint32_t)k < cnt && !term && s_ < 64 && u < n_valid) {
                         const int val = dc ? (int)(((e & 0x7ffu) | ((e >> 1) & 0x800u)) << 20) >> 20 : (int)(e << 21) >> 21;
-                        if (s_ == 52 && quirk) s52[u] = 0x80000000u | ((uint32_t)val & 0xffffu);   // overrides slot 48 at natural 38, even when zero
-                        else {
-                            const uint32_t qe = dc ? 1u : qz[comp_of[u]][s_];
-                            tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
-                        }
+                        const uint32_t qe = dc ? 1u : qz[comp_of[u]][s_];               // (slot 52 under the quirk: position 64, quantiser 1)
+                        tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
                     }
                     if ((uint32_t)k < cnt) {
                         slot = s_ + 1;
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     if (wv != 0) {
         for (uint32_t i = tid - 64; i < n_du * 7; i += PJD_IDCT_THREADS - 64) {
             const uint32_t u = i / 7, r = 1 + (i - u * 7);
-            if (r == 4 && s52[u]) tile[u][38] = (int16_t)pjd_dequant((int)(int16_t)(s52[u] & 0xffffu), qz[comp_of[u]][48] & 0xffffu);   // slot 48 -> natural 38
+            if (r == 4 && tile[u][64] != (int16_t)PJD_COEF_SENTINEL) tile[u][38] = (int16_t)pjd_dequant((int)tile[u][64], qz[comp_of[u]][48] & 0xffffu);   // slot 52 over natural 38 (the quantiser of slot 48 is that position's)
             pjd_tile_row(tile, u, r);
         }
     } else {
