@@ -61,7 +61,9 @@
                                     // A chain of non-merging lanes that crosses k wave boundaries needs k + 2 generations; never a chain over the whole image.
 #define PJD_SYNC_MAX_ITERS 72       // re-sync rounds per wave before giving up (a non-merging chain moves one lane per round)
 #define PJD_DC_BLOCK       256      // lanes per DC-prediction scan block
+#ifndef PJD_IDCT_THREADS
 #define PJD_IDCT_THREADS   256
+#endif
 #ifndef PJD_IDCT_MAX_DU
 #define PJD_IDCT_MAX_DU    96       // data units staged in LDS per IDCT workgroup (<= PJD_IDCT_THREADS); with the group parser (round 3): 72 / 90 / 96 -> 0.59 / 0.53 / 0.525 ms on cfg3
 #endif
