@@ -35,9 +35,9 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct in this header changes size or layout (pjd_image_desc gained qt_slot48 and
  * pjd_batch_info grew in version 2; version 3 added the coefficient download and pjd_split_*; version 4 the progressive scans of
- * pjd_image_desc and the exact-path figures of pjd_batch_info).
+ * pjd_image_desc and the exact-path figures of pjd_batch_info; version 5 pjd_batch_info::n_steps).
  * A caller built against another version must not pass its structs: check pjd_version() == PJD_VERSION after loading.     */
-#define PJD_VERSION 4
+#define PJD_VERSION 5
 
 /* ---- error codes (library level) ---------------------------------------- */
 #define PJD_OK              0
@@ -161,7 +161,7 @@ typedef struct pjd_batch_info {
     uint64_t device_bytes;             /* everything this batch holds in HBM                  */
     int32_t  n_sequential;             /* images routed to the exact one-lane kernel up front */
     int32_t  n_fallback;               /* images re-decoded by it after the last decode       */
-    uint64_t n_huff_workgroups;        /* Huffman workgroups (up to 4 waves of 64 lanes, one table set) */
+    uint64_t n_huff_workgroups;        /* Huffman workgroups (up to 2 waves of 64 lanes, one table set) */
     /* diagnostics of the last decode: self-synchronisation effort                           */
     uint64_t sync_rounds;              /* re-sync rounds summed over workgroups               */
     uint64_t sync_lane_passes;         /* lanes that re-decoded their subsequence, summed     */
@@ -183,6 +183,8 @@ typedef struct pjd_batch_info {
     uint32_t reserved_;
     uint64_t walks, walk_lanes;        /* last decode: re-sync rounds that a wave finished as a cooperative walk (few lanes left: the
                                           whole wave decodes one lane's subsequence several times faster), and the lanes walked */
+    uint64_t n_steps;                  /* last decode: steps of the write pass (a step emits one entry, or the two entries of a symbol
+                                          pair that one table lookup yields): n_entries / n_steps = symbols per step               */
 } pjd_batch_info;
 
 /* ---- context --------------------------------------------------------------- */

@@ -692,6 +692,7 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
         info->walks = st[PJD_STAT_WALKS]; info->walk_lanes = st[PJD_STAT_WALKS + 1];
         for (int r = 0; r < PJD_FLAG_REASONS && r < 8; r++) info->flag_waves[r] = st[PJD_STAT_FLAG0 + r];
         info->n_entries = st[PJD_STAT_ENTRIES];               // entries the lanes emitted in the last decode
+        info->n_steps = st[PJD_STAT_STEPS];                   // ... in this many steps of the write pass
     }
     info->n_huff_workgroups = P.hwgs.size();
     if (b->dev.dbg && b->decoded) {          // PJD_DEBUG_STATS: wave timeline of the last decode (units of 10 ns)
@@ -751,7 +752,7 @@ int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pj
     std::memset(info, 0, sizeof *info);
     info->n_images = (int32_t)P.images.size();
     info->pixels = P.pixels; info->ecs_bytes = P.ecs_bytes; info->out_bytes = P.out_bytes;
-    info->coef_bytes = P.n_du * 64 * sizeof(int16_t);
+    info->coef_bytes = P.n_ent * 2 + P.n_words * 4 + P.dense_du * 128;      // as pjd_batch_get_info: lane streams + transposed words + dense scratch
     info->n_data_units = P.n_du;
     info->n_subsequences = P.subs.size();
     info->n_sequential = (int32_t)P.seq_images.size();

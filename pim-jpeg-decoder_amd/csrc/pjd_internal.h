@@ -17,9 +17,7 @@
 #ifndef PJD_NCHK
 #define PJD_NCHK           4        // checkpoints per subsequence (trajectory states a re-sync bridge can merge into); a power of two
 #endif
-#ifndef PJD_STAGE_ENTRIES
-#define PJD_STAGE_ENTRIES  16       // entries a lane stages in LDS between flushes (a power of two, multiple of 8)
-#endif
+#define PJD_STAGE_ENTRIES  16       // slots a lane stages in LDS between flushes: one group (a head + 7 step words)
 #define PJD_CHK_BYTES      (2 * PJD_NCHK * 64 * 4)
 #define PJD_STAGE_BYTES    (PJD_STAGE_ENTRIES * 2 * 64)
 // per wave: checkpoints (sync passes) / entry staging (write pass).  LDS sets the kernel's occupancy; measured in
@@ -72,33 +70,38 @@
 // Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
 // the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
 #define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
-// Slots (2 bytes each) of a lane's region.  Every symbol consumes at least `min_bits` bits
-// of stream -- the smallest (code length + value bits) over the Huffman tables the batch uses, computed by the planner; 1 if a
-// table has a 1-bit code for a size-0 symbol -- so a lane of `sub_bytes` bytes emits at most 8 * sub_bytes / min_bits entries,
-// plus the symbol that may have started before it and some slack.  (Annex-K tables: 2 bits; optimised tables of very
-// low qualities reach 1.5 bits per symbol on average -- a 1-bit EOB after a 2-bit DC code -- but no single symbol below 1.)
-// A region is a sequence of 32-byte GROUPS: two slots of head + PJD_GROUP_ENTRIES (14) entries (below), so the capacity in slots is
-// 16 / 14 of the entry bound, a whole number of groups.  The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.
-#define PJD_GROUP          16       // slots per group = entries the write pass stages between two flushes
-#define PJD_GROUP_ENTRIES  (PJD_GROUP - 2)
-#define PJD_LANE_CAP(sub_bytes, min_bits)   ((((8u * (sub_bytes) + (min_bits) - 1) / (min_bits) + 64u + PJD_GROUP_ENTRIES - 1) / PJD_GROUP_ENTRIES + 1u) * PJD_GROUP)
+// Slots (2 bytes each) of a lane's region.  The write pass emits one 32-bit STEP word per decode step -- one symbol, or the PAIR of
+// symbols one table lookup yields (below) -- and every symbol consumes at least `min_bits` bits of stream: the smallest (code length +
+// value bits) over the Huffman tables of the PICTURE's table set, computed by the planner; 1 if a table has a 1-bit code for a
+// size-0 symbol.  So a lane of `sub_bytes` bytes takes at most 8 * sub_bytes / min_bits steps, plus the symbol that may have
+// started before it and some slack.  (Annex-K tables: 2 bits; optimised tables of dense pictures: 2-4.)
+// A region is a sequence of 32-byte GROUPS: one head word + PJD_GROUP_STEPS (7) step words (below), a whole number of groups.
+// The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.
+#define PJD_GROUP          16       // slots per group = what the write pass stages between two flushes (8 dwords)
+#define PJD_GROUP_STEPS    (PJD_GROUP / 2 - 1)
+#define PJD_LANE_CAP(sub_bytes, min_bits)   ((((8u * (sub_bytes) + (min_bits) - 1) / (min_bits) + 64u + PJD_GROUP_STEPS - 1) / PJD_GROUP_STEPS + 1u) * PJD_GROUP)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
-// The write pass turns every decoded Huffman symbol into exactly one 16-bit entry:
-//   DC symbol            bits 10..0 = diff[10:0], bit 12 = diff[11], bit 11 = 0, other bits 0   (12-bit two's complement)
-//   AC run/size symbol   bits 15..12 = run, bit 11 = "unit complete" (this coefficient lands on slot 63),
-//                        bits 10..0 = value (11-bit two's complement; 0 for a size-0 symbol such as ZRL)
-//   EOB                  0x0800: run 0, value 0, "unit complete"
-// A unit is [DC][AC ...] up to and including the first entry with bit 11 set; the slot of an AC entry is the
-// running sum of (run + 1) over the unit.  A size-0 symbol stores an explicit 0 (reference
-// src/jpeg_scanner.cpp:516-517), which matters at slot 52 only (zigzag quirk).
-// Entries are kept in GROUPS of 16 slots = 32 bytes, the unit the write pass flushes: slots 0..1 hold the group's HEAD, one 32-bit
-// word `[units completed in this lane before the group's first entry : 24][zigzag slot that entry fills from : 8]` (slot 0: the entry
-// is a unit's DC difference; else the AC coefficient lands on slot + run), slots 2..15 hold 14 entries.  With the head a back-end
-// thread parses its group without looking at anything before it (pjd_k_idct_colour_lanes); the head travels in the same 32-byte
-// store as its entries (kept in an array of its own it cost 64 bytes of HBM traffic per 4-byte word, profiles/r03_experiments.md).
-// Positions in a lane's region (PjdDevLaneInfo::n_ent, PjdDevMark::ent_off) count SLOTS, heads included.
-#define PJD_ENT_LAST       0x0800u
+// The write pass turns every decoded Huffman symbol into one 16-bit entry; a STEP word holds the one or two entries of a step:
+// low half = entry A, high half = entry B (the second symbol of a pair) or PJD_ENT_NONE.
+//   DC symbol            the step's low half IS the DC difference as int16 (12 significant bits); a DC symbol is never part of a
+//                        pair, the high half is PJD_ENT_NONE.  Which steps hold a DC difference follows from the position: the
+//                        first entry of every data unit.
+//   AC run/size symbol   bits 15..5 = value (11-bit two's complement; 0 for a size-0 symbol such as ZRL), bits 4..0 = run + 1
+//                        (1..16): the coefficient lands on slot (next free slot + run)
+//   EOB                  0x0000: "run + 1" = 0, value 0 -- completes the unit, stores nothing
+//   PJD_ENT_NONE         0x001f ("run + 1" = 31): no entry (only in the high half)
+// A unit is [DC][AC ...] up to and including an EOB or the entry that lands on slot 63 (next free slot = 64).  A size-0 symbol
+// stores an explicit 0 (reference src/jpeg_scanner.cpp:516-517), which matters at slot 52 only (zigzag quirk).
+// Steps are kept in GROUPS of 8 dwords = 32 bytes, the unit the write pass flushes: dword 0 is the group's HEAD, `[units completed
+// in this lane before the group's first entry : 24][zigzag slot that entry fills from : 8]` (slot 0: the entry is a unit's DC
+// difference; else the AC coefficient lands on slot + run), dwords 1..7 hold 7 steps.  With the head a back-end thread parses its
+// group without looking at anything before it (pjd_k_idct_colour_lanes); the head travels in the same 32-byte store as its steps.
+// Positions in a lane's region (PjdDevLaneInfo::n_ent, PjdDevMark::ent_off) count 16-bit SLOTS, heads included (always even).
+// Round 4: the write pass used to emit one entry per step (one symbol); with the pair tables it takes two symbols in 60 % of
+// its steps on dense streams, and a step's two entries travel in one LDS word whatever the other lanes of the wave decoded.
+#define PJD_ENT_NONE       0x001fu
+#define PJD_ENT_EOB        0x0000u
 
 // ---- image flags (device side) -----------------------------------------------------
 #define PJD_IF_STANDARD_RESTART 1u  // restart every RI-th MCU; else the reference's (y*Wr+x)%RI rule
@@ -140,6 +143,7 @@ enum {
 };
 #define PJD_STAT_FLAG0 4
 #define PJD_STAT_ENTRIES 11  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
+#define PJD_STAT_STEPS   14  // step words they took for it (a step holds one symbol or a pair)
 #define PJD_STAT_WALKS   12  // cooperative walks (a wave taking over its few remaining active lanes), 13: lanes walked in them
 
 struct PjdDevImage {
@@ -170,6 +174,9 @@ struct PjdDevImage {
     uint8_t  walk_max;                 // re-sync rounds with at most this many active lanes are walked cooperatively (0: never)
     uint8_t  pad_;
     uint32_t pscan_base, n_pscan;      // progressive frames: their scans in PjdDevBatch::pscans
+    uint32_t lane_cap;                 // slots of one lane region of THIS image: PJD_LANE_CAP(sub_bytes, min symbol bits of its table set)
+    uint32_t pad2_;
+    uint64_t ent_base;                 // first slot of lane `lane_base` in PjdDevBatch::ent; lane q of the image owns [ent_base + (q - lane_base) * lane_cap, + lane_cap)
 };
 
 // raw Huffman table as shipped by the host (reference HuffmanTable, jpeg.h:129-134)
@@ -197,11 +204,12 @@ struct PjdDevScan {
 // every field the per-symbol loops need comes out with one AND or one bit-field extract, and the zigzag bookkeeping is ONE
 // subtraction (see PJD_LUT_ADV):
 //   bits  4..0  bits consumed by the symbol (code length + value bits), 1..27; 0 marks a pointer entry (below)
-//   bits 10..5  "advance": run + 1 for an AC run/size symbol, 1 for a DC symbol, 33 for an EOB
-//   bit  11     EOB (AC tables only).  Bits 11..5 read as ONE 7-bit number are the slots the symbol uses up -- 97 for an EOB,
+//   bits 10..5  "advance": run + 1 for an AC run/size symbol, 1 for a DC symbol, 32 for an EOB
+//   bit  11     EOB (AC tables only).  Bits 11..5 read as ONE 7-bit number are the slots the symbol uses up -- 96 for an EOB,
 //               more than any unit has left -- so "63 - slot" minus that number going negative is "the unit is complete";
 //               a run/size symbol that lands past slot 63 (an error in the reference, jpeg_scanner.cpp:500) leaves -16..-2 there,
-//               an EOB -97..-35, a unit that ends exactly on slot 63 leaves -1: the write pass tells them apart with one minimum
+//               an EOB -96..-34, a unit that ends exactly on slot 63 leaves -1: the write pass tells them apart with one minimum.
+//               The low five bits of that number are the "run + 1" field of the symbol's lane-stream entry (0 for an EOB)
 //   bits 15..12 value bits (size) 0..11, or an invalid symbol (the code alone is consumed):
 //               14 = the reference's "symbol 0xFF": no code starts with these bits (then 16 bits are consumed, as its
 //                    get_next_symbol does), or the table really holds the symbol 0xFF (jpeg_scanner.cpp:470,490)
@@ -213,7 +221,8 @@ struct PjdDevScan {
 // first symbol whole (code and value bits), it is a valid run/size symbol (not an EOB), and the rest of the 9 bits determine the next code
 // (any valid AC symbol, an EOB too; its value bits may lie outside):
 //   bits 20..16 bits consumed by both symbols (2..27+; 0: no pair here)        bits 27..21 slots both use up (advance 1 + advance 2)
-// The state-only passes take a pair in ONE step when the first symbol neither completes the unit nor reaches the next checkpoint /
+//   bits 31..28 value bits (size) of the second symbol (its value is the last `size` of the bits both consume)
+// Every pass takes a pair in ONE step when the first symbol neither completes the unit nor reaches the next checkpoint /
 // subsequence end: dense streams average 5 bits per symbol, 60 % of the steps there are pairs (profiles/r03_experiments.md).
 // Canonical codes keep all long codes in one contiguous range of prefixes [p0, p1), so the second level
 // costs 256 bytes per long prefix.
@@ -226,10 +235,11 @@ struct PjdDevTset {
     uint16_t l2_p1[PJD_MAX_TABLES];
 };
 #define PJD_LUT_USED(e)  ((e) & 31u)
-#define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 97 for an EOB
+#define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 96 for an EOB
 #define PJD_LUT_SIZE(e)  (((e) >> 12) & 15u)
 #define PJD_LUT_PAIR_USED(e)  (((e) >> 16) & 31u)  // of an L1 entry: 0 = no pair
 #define PJD_LUT_PAIR_ADV(e)   (((e) >> 21) & 127u)
+#define PJD_LUT_PAIR_SIZE2(e) ((e) >> 28)
 #define PJD_LUT_EOB      0x0800u
 #define PJD_LUT_BADSYM   14u
 #define PJD_LUT_BADLEN   15u
@@ -270,7 +280,7 @@ struct PjdDevIdctWg {                  // one IDCT/colour workgroup = one coeffi
 
 // what a Huffman lane leaves behind for the back end (written at the end of its write pass)
 struct PjdDevLaneInfo {
-    uint32_t n_ent;                    // slots used in the lane's region (group heads included)
+    uint32_t n_ent;                    // slots used in the lane's region (group heads included; two per step word)
     uint32_t first_du;                 // bits 27..0: image-relative index of the data unit the lane's first entry belongs to (a unit may span lanes);
                                        // bit 31: the lane starts a restart segment (DC predictors are zero there)
     uint16_t dc_sum[3];                // sum of the DC differences decoded in this lane, per component (mod 2^16)

@@ -9,12 +9,12 @@
 //   pjd_k_idct_colour_lanes / pjd_k_idct_colour
 //                       fused de-zigzag + dequantise + 8x8 IDCT + chroma upsample + YCbCr->RGB + raster / BMP store
 //                       (reference src/decoder_dpu.c:158-390 and src/bmp_writer.cpp:43-65 for the BMP row order).
-//                       _lanes parses the parallel decoder's lane streams (one 16-bit entry per symbol);
-//                       the other reads the dense int16 scratch the exact kernel fills.
+//                       _lanes parses the parallel decoder's lane streams (one 16-bit entry per symbol, one or two per
+//                       step word); the other reads the dense int16 scratch the exact kernel fills.
 //
-// HBM-bound integer work: coefficients are read once with 16-byte loads, tiles
-// live in LDS (row stride 144 B so that the column pass is bank-conflict free),
-// pictures are written once.
+// Integer work bound by VALU instruction issue (profiles/r03_cfg3.md: valu_issue_frac 1.0 -- the entry parser is its largest
+// phase), not by HBM: coefficients are read once with 16-byte loads, tiles live in LDS (row stride 144 B so that the column
+// pass is bank-conflict free), pictures are written once.
 #include <cstdlib>
 
 #include "pjd_device_common.h"
@@ -653,7 +653,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 
     // units of this range that were decoded: all, unless the picture's first entropy-coding error lies in or before the range (the
     // others keep zero coefficients, as in the reference, whose buffers start zeroed and which stops at the error)
-    const uint32_t n_valid = pjd_units_decoded(B.imstate[wg.image].err_key, wg.first_mcu * dus, n_du);
+    const unsigned long long err_key = B.imstate[wg.image].err_key;
+    const uint32_t n_valid = pjd_units_decoded(err_key, wg.first_mcu * dus, n_du);
+    const uint32_t err_byte = (uint32_t)(err_key >> 35);       // byte of the stream the offending symbol starts in (bit positions fit 32 bits); no error: past every lane
     const PjdDevMark mark = B.marks[blockIdx.x];
     const uint32_t lane_end = im.lane_base + im.n_lane;
     uint32_t q = mark.lane, n = mark.ent_off;
@@ -699,7 +701,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                     const PjdDevLaneInfo li = B.lane_info[ql];
                     fd = (li.first_du & 0x0fffffffu) - U0;                  // "negative" for the lane the range starts in
                     ne = li.n_ent;
-                    const bool in = ql == q || (int)fd < (int)n_valid;
+                    // a lane that starts BEHIND the picture's first entropy-coding error holds what the reference never decoded; when the
+                    // erring unit was still open at the error (an error in its AC part), that lane's leading entries would land in it
+                    const bool in = (ql == q || (int)fd < (int)n_valid) && (ql == q || B.lanes[ql].byte_start <= err_byte);
                     if (in && ql <= q_end) {
                         const uint32_t gs = ql == q ? g0 : 0u, all = (ne + PJD_GROUP - 1) / PJD_GROUP;
                         uint32_t ge = ql == q_end ? (g_end + 1 < all ? g_end + 1 : all) : all;
@@ -723,29 +727,49 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                 const uint32_t ql = qw + li_;
                 const uint32_t g = w - ltab[li_] + (ql == q ? g0 : 0u);
                 const uint32_t ne = ltab[64 + li_];
-                const uint32_t cnt = ne - g * PJD_GROUP < PJD_GROUP ? ne - g * PJD_GROUP : PJD_GROUP;
-                const uint4 *src = reinterpret_cast<const uint4 *>(B.ent + (size_t)ql * B.lane_cap + (size_t)g * PJD_GROUP);
+                const uint32_t cnt = ne - g * PJD_GROUP < PJD_GROUP ? ne - g * PJD_GROUP : PJD_GROUP;      // slots of this group that are in use (even)
+                const uint4 *src = reinterpret_cast<const uint4 *>(B.ent + im.ent_base + (size_t)(ql - im.lane_base) * im.lane_cap + (size_t)g * PJD_GROUP);
                 const uint4 r0 = src[0], r1 = src[1];                       // the group: 32 bytes, 32-byte aligned
                 const uint32_t wds[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
                 const uint32_t head = wds[0];
                 uint32_t u = ltab[32 + li_] + (head >> 8);                  // unit of the group's first entry, relative to the range ("negative" before it)
-                uint32_t slot = head & 63u;                                 // 0: that entry is a DC difference
+                uint32_t slot = head & 63u;                                 // 0: that entry is a DC difference; else the next free zigzag slot of the open unit
 #pragma unroll
-                for (int k = 2; k < PJD_GROUP; k++) {
-                    const uint32_t e = (k & 1) ? wds[k >> 1] >> 16 : wds[k >> 1] & 0xffffu;
-                    // ONE path for both kinds of entry (the lanes of a wave stand at DC and AC entries at once): a DC difference (slot == 0) is
-                    // "a coefficient for position 0 with quantiser 1" -- its raw 12-bit value waits in the tile for the DC stage
-                    const bool dc = slot == 0;
-                    const uint32_t s_ = dc ? 0u : slot + (e >> 12);
-                    const bool term = !dc && (e & 0xf7ffu) == 0;                 // EOB: completes the unit, stores nothing
-                    if ((uint32_t)k < cnt && !term && s_ < 64 && u < n_valid) {
-                        const int val = dc ? (int)(((e & 0x7ffu) | ((e >> 1) & 0x800u)) << 20) >> 20 : (int)(e << 21) >> 21;
-                        const uint32_t qe = dc ? 1u : qz[comp_of[u]][s_];               // (slot 52 under the quirk: position 64, quantiser 1)
-                        tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
+                for (int k = 1; k < PJD_GROUP / 2; k++) {                   // the group's step words: entry A, and entry B unless it is PJD_ENT_NONE
+                    const uint32_t sw = wds[k];
+                    const bool on = (uint32_t)(2 * k) < cnt;
+                    {   // A: ONE path for both kinds of entry (the lanes of a wave stand at DC and AC entries at once): a DC difference
+                        // (slot == 0) is "a coefficient for position 0 with quantiser 1" -- its raw value waits in the tile for the DC stage
+                        const bool dc = slot == 0;
+                        const uint32_t f = sw & 31u;                        // run + 1; 0: EOB
+                        const uint32_t pos = dc ? 0u : slot + f - 1u;       // an EOB gives slot - 1: stores nothing (below)
+                        if (on && (dc || f != 0) && pos < 64 && u < n_valid) {
+                            const int val = dc ? (int)(int16_t)(sw & 0xffffu) : (int)(sw << 16) >> 21;
+                            const uint32_t qe = dc ? 1u : qz[comp_of[u]][pos];             // (slot 52 under the quirk: position 64, quantiser 1)
+                            tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
+                        }
+                        if (on) {
+                            const uint32_t ns = dc ? 1u : slot + f;
+                            const bool last = !dc && (f == 0 || ns > 63);   // EOB, or the entry landed on slot 63 (or past it: a broken stream)
+                            slot = last ? 0u : ns;
+                            u += last ? 1u : 0u;
+                        }
                     }
-                    if ((uint32_t)k < cnt) {
-                        slot = s_ + 1;
-                        if (!dc && (e & PJD_ENT_LAST)) { u++; slot = 0; }
+                    {   // B: the second symbol of a pair -- an AC entry of the unit A left open
+                        const uint32_t f = (sw >> 16) & 31u;
+                        const bool onb = on && f <= 16;                     // PJD_ENT_NONE: "run + 1" = 31
+                        const uint32_t pos = slot + f - 1u;
+                        if (onb && f != 0 && pos < 64 && u < n_valid) {
+                            const int val = (int)sw >> 21;
+                            const uint32_t qe = qz[comp_of[u]][pos];
+                            tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
+                        }
+                        if (onb) {
+                            const uint32_t ns = slot + f;
+                            const bool last = f == 0 || ns > 63;
+                            slot = last ? 0u : ns;
+                            u += last ? 1u : 0u;
+                        }
                     }
                 }
             }

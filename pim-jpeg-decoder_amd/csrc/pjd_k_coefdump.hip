@@ -65,31 +65,38 @@ __global__ __launch_bounds__(64) void pjd_k_coefdump_lanes(PjdDevBatch B, uint32
     uint32_t slot = 0, comp = 0;
     size_t base = 0;
     bool in_unit = false;
+    bool second = false;                     // the next entry to take is the high half of the step word at n
+    const uint16_t *region = B.ent + im.ent_base + (size_t)(q - im.lane_base) * im.lane_cap;
     while (D < D_stop) {
         if (n >= n_ent) {
-            q++; n = 0;
+            q++; n = 0; second = false;
             if (q >= lane_end) break;
             n_ent = B.lane_info[q].n_ent;
+            region = B.ent + im.ent_base + (size_t)(q - im.lane_base) * im.lane_cap;
             continue;
         }
         if ((n & (PJD_GROUP - 1)) < 2) { n = (n & ~(uint32_t)(PJD_GROUP - 1)) + 2; continue; }      // a group's head (pjd_internal.h)
-        const uint32_t e = B.ent[(size_t)q * B.lane_cap + n];
-        n++;
-        if (!in_unit) {                      // DC entry (layout: pjd_internal.h): 12-bit two's complement difference
+        // a step word: entry A, then entry B unless it is PJD_ENT_NONE
+        const uint32_t e = region[n + (second ? 1u : 0u)];
+        if (second) { second = false; n += 2; if ((e & 31u) > 16u) continue; }
+        else second = true;
+        if (!in_unit) {                      // DC entry (layout: pjd_internal.h): the difference as int16
             const uint32_t m = D / dus, kk = D - m * dus;
             if (kk == 0 && (m == im.first_mcu || (RI != 0 && m % RI == 0))) pred[0] = pred[1] = pred[2] = 0;   // jpeg_scanner.cpp:723-727
             base = ref_unit_base(im, D, comp);
-            const int diff = (int)(((e & 0x7ffu) | ((e >> 1) & 0x800u)) << 20) >> 20;
+            const int diff = (int)(int16_t)e;
             pred[comp] = (int)(int16_t)(pred[comp] + diff);                                                      // :485-486
             out[base] = (int16_t)pred[comp];
             slot = 0;
             in_unit = true;
             continue;
         }
-        const bool last = (e & PJD_ENT_LAST) != 0;
-        if ((e & 0xf7ffu) != 0) {            // not EOB: run / value, stored through the zigzag map (:517)
-            slot += (e >> 12) + 1;
-            if (slot < 64) out[base + ref_natural(im, slot)] = (int16_t)((int)(e << 21) >> 21);
+        const uint32_t f = e & 31u;          // run + 1; 0: EOB
+        bool last = f == 0;
+        if (f != 0) {                        // run / value, stored through the zigzag map (:517)
+            slot += f;
+            if (slot < 64) out[base + ref_natural(im, slot)] = (int16_t)((int)(e << 16) >> 21);
+            if (slot >= 63) last = true;
         }
         if (last) { in_unit = false; D++; }
     }

@@ -29,16 +29,21 @@
 //                           published 64-bit words (PJD_GENS generations, never a chain over the image)
 //                        C  data-unit counts: scan inside the wave, decoupled look-back over the image's waves
 //                        W  write pass from the true entry states: EVERY symbol becomes one 16-bit entry in the
-//                           lane's own region (layout: pjd_internal.h), staged through LDS and written as whole
-//                           64-byte pieces; the lane that decodes the first DC symbol of an IDCT workgroup's
+//                           lane's own region, one 32-bit STEP word per step -- a symbol, or the pair of symbols one
+//                           lookup yields (layout: pjd_internal.h) -- staged through LDS and written as whole
+//                           32-byte groups; the lane that decodes the first DC symbol of an IDCT workgroup's
 //                           range leaves a mark (lane, entry offset, DC sums so far); per lane: entry count and
 //                           DC sums for the predictor scan (pjd_k_lane_dc_*)
 //
 // Exactness: a lane that starts from the true state performs exactly the reference's
-// decode_MCU_component (reference src/jpeg_scanner.cpp:467-520).  Anything irregular seen in the
-// write pass -- invalid code, size or run outside the baseline limits, a segment that ends early or
-// late, a boundary that did not stitch, a lane that does not reproduce its synchronised exit --
-// sets PJD_STW_NEEDS_EXACT and the host re-decodes that image with the one-lane exact kernel.
+// decode_MCU_component (reference src/jpeg_scanner.cpp:467-520).  An entropy-coding error of the true
+// decode -- invalid code, size or run outside the baseline limits, the data ending inside a symbol --
+// is settled by the lane that meets it (careful_span: the reference's checks in the reference's order;
+// the picture's first error becomes its status, pjd_k_image_verdict).  What the parallel decoder cannot
+// resolve -- a segment that ends early or late, a boundary that did not stitch, a lane that does not
+// reproduce its synchronised exit -- is reported with its position (PjdDevImState::flag_pos); only if
+// that lies before the picture's first error does pjd_batch_sync re-decode the picture with the
+// one-lane exact kernel, on the GPU.
 #include <cstdlib>
 
 #include "pjd_device_common.h"
@@ -48,7 +53,7 @@
 static_assert(sizeof(PjdDevHuffRaw) == 180, "raw table layout");
 static_assert(PJD_LUT_BITS + PJD_L2_BITS == 16 && PJD_L1_BYTES == (4 << PJD_LUT_BITS), "two-level table geometry");
 static_assert(PJD_HUFF_LANES == 64, "one wave per 64 lanes");
-static_assert(PJD_STAGE_ENTRIES == PJD_GROUP, "a group (head + 14 entries) is what one flush of the staging buffer writes");
+static_assert(PJD_STAGE_ENTRIES == PJD_GROUP && PJD_GROUP == 16, "a group (a head word + 7 step words) is what one flush of the staging buffer writes");
 
 #define LUT_BAD     PJD_LUT_ENTRY(16u, 1u, false, PJD_LUT_BADSYM)    // no code: consume 16 bits (as the reference's get_next_symbol)
 
@@ -67,7 +72,7 @@ __device__ __forceinline__ uint32_t lut_entry(uint32_t len, uint32_t sym, bool i
         size = sym;
         if (sym > 11 && !bad) bad = PJD_LUT_BADLEN;                     // jpeg_scanner.cpp:474
     }
-    return PJD_LUT_ENTRY(len + (bad ? 0u : size), eob ? 33u : run + 1, eob, bad ? bad : size);   // EOB: 33 + 64 = 97 slots (pjd_internal.h)
+    return PJD_LUT_ENTRY(len + (bad ? 0u : size), eob ? 32u : run + 1, eob, bad ? bad : size);   // EOB: 32 + 64 = 96 slots (pjd_internal.h)
 }
 
 __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
             const uint32_t rest = PJD_LUT_BITS - PJD_LUT_USED(m);
             const uint32_t m2 = match(idx & ((1u << rest) - 1u), rest, 1, rest);
             if (m2 && PJD_LUT_SIZE(m2) < PJD_LUT_BADSYM && PJD_LUT_USED(m) + PJD_LUT_USED(m2) <= 31u)
-                pair = (PJD_LUT_USED(m) + PJD_LUT_USED(m2)) | ((PJD_LUT_ADV(m) + PJD_LUT_ADV(m2)) << 5);
+                pair = (PJD_LUT_USED(m) + PJD_LUT_USED(m2)) | ((PJD_LUT_ADV(m) + PJD_LUT_ADV(m2)) << 5) | (PJD_LUT_SIZE(m2) << 12);   // size 2: bits 31..28 of the entry
         }
         L1[idx] = (e & 0xffffu) | (pair << 16);
     }
@@ -518,11 +523,12 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
 // ---------------------------------------------------------------------------------------------
 struct OutCtx {
     uint16_t *region;      // the lane's entry region (HBM)
-    uint32_t *stage;       // LDS: [16 rows][64 lanes] dwords at this lane's column: two entries per dword
-    uint32_t cap;          // entries the region holds
-    uint32_t n;            // slots used so far (pjd_internal.h: groups of a 2-slot head + 14 entries); even whenever a step begins
+    uint32_t *stage;       // LDS: [8 rows][64 lanes] dwords at this lane's column: row 0 the group's head, rows 1..7 its step words
+    uint32_t cap;          // slots the region holds
+    uint32_t n;            // slots used so far (pjd_internal.h: groups of a head word + 7 step words); even
+    uint32_t npair;        // steps that held a pair (symbols = steps + pairs)
     uint32_t dcA, dcB;     // DC differences summed so far, each mod 2^16: Y (low) Cb (high) | Cr (low)
-    uint32_t left;         // data units to complete before the next unit that starts an IDCT workgroup's range
+    uint32_t mark_D;       // the next data unit that opens an IDCT workgroup's range
     uint32_t ru;           // data units per IDCT workgroup
     PjdDevMark *marks;     // of this image
     uint32_t mark_next;    // index of the next mark this lane would write
@@ -531,10 +537,10 @@ struct OutCtx {
     uint32_t D_in;         // the lane's first data unit
 };
 
-// 16 dwords of the lane's staging column -> 64 bytes of its region
-__device__ __forceinline__ void stage_flush(const OutCtx &O, uint32_t first_entry)
+// 8 dwords of the lane's staging column -> 32 bytes of its region
+__device__ __forceinline__ void stage_flush(const OutCtx &O, uint32_t first_slot)
 {
-    uint4 *dst = reinterpret_cast<uint4 *>(O.region + first_entry);
+    uint4 *dst = reinterpret_cast<uint4 *>(O.region + first_slot);
 #pragma unroll
     for (int k = 0; k < PJD_STAGE_ENTRIES / 8; k++) {
         uint4 v;
@@ -550,7 +556,7 @@ struct WState {            // decoder state of the write pass, in registers
     uint32_t ra, x;        // phase record address, table offsets of the current unit
     uint32_t mA, mB;       // DC-sum selectors of the current unit's component
     uint32_t emax;         // max over the table entries seen: >= 0xe000 <=> an invalid symbol (size field 14 or 15)
-    uint32_t umin;         // min over the symbols of (63 - slot after the symbol) + 16, unsigned: <= 14 <=> a run past slot 63
+    uint32_t umin;         // min over the steps of (63 - slot after the step) + 16, unsigned: <= 14 <=> a run past slot 63
 };
 
 typedef unsigned short pjd_u16x2 __attribute__((ext_vector_type(2)));
@@ -559,38 +565,58 @@ __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, (pjd_u16x2)(__builtin_bit_cast(pjd_u16x2, a) + __builtin_bit_cast(pjd_u16x2, b)));
 }
 
-// One symbol of the write pass.  Returns the 16-bit entry; updates the state.
-__device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState &S, uint32_t &D, OutCtx &O)
+// `size` value bits sign-extended the JPEG way (reference src/jpeg_scanner.cpp:478-484,510-516)
+__device__ __forceinline__ int jpeg_extend(uint32_t bits, uint32_t size)
+{
+    const uint32_t m1 = 1u << size;
+    return (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
+}
+// the same for the `size` bits that END `used` bits into the window pk (used <= 32): a leading 0 bit means bits - (2^size - 1)
+__device__ __forceinline__ int jpeg_value(uint32_t pk, uint32_t used, uint32_t size)
+{
+    const uint32_t off = 32u - used;
+    const uint32_t b = __builtin_amdgcn_ubfe(pk, off, size);
+    const uint32_t m = (1u << size) - 1u;
+    const uint32_t top = (uint32_t)__builtin_amdgcn_sbfe(pk, off + size - 1u, 1u);      // all ones if the leading bit is set (size 0: m == 0 anyway)
+    return (int)(b - (m & ~top));
+}
+
+// One STEP of the write pass: one symbol, or the PAIR the table entry holds (AC symbols, the first leaves the unit open and the
+// second still starts before `end_bit`).  Returns the step word (entry A | entry B << 16, pjd_internal.h); updates the state.
+__device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState &S, uint32_t &D, OutCtx &O, uint32_t end_bit)
 {
     const bool is_dc = (S.zb == 63);
-    if (__builtin_expect(is_dc && O.left == 0, 0)) {                        // this unit opens an IDCT workgroup's range
+    if (__builtin_expect(is_dc && D == O.mark_D, 0)) {                      // this unit opens an IDCT workgroup's range
         PjdDevMark m;
         m.lane = O.lane_q; m.ent_off = O.n;
         m.acc[0] = (uint16_t)O.dcA; m.acc[1] = (uint16_t)(O.dcA >> 16); m.acc[2] = (uint16_t)O.dcB; m.pad_ = 0;
         O.marks[O.mark_next++] = m;
-        O.left = O.ru;
+        O.mark_D += O.ru;
     }
     const uint32_t pk = w.peek();
     const uint4 nx = lds_u32x4(S.ra);                                       // the unit after this one
     const uint32_t tab = is_dc ? (S.x & 0xffffu) : (S.x >> 16);
-    const uint32_t e = lut_lookup(lbase, tab, pk);
-    const uint32_t used = PJD_LUT_USED(e), size = PJD_LUT_SIZE(e), adv = PJD_LUT_ADV(e);
-    // value: `size` bits after the code, sign-extended the JPEG way (jpeg_scanner.cpp:478-484,510-516); an invalid entry
-    // (size field 15) yields garbage here and sends the picture to the exact kernel through S.emax
-    const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size);
-    const uint32_t m1 = 1u << size;
-    const int val = (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
+    const uint32_t e = lut_lookup_pair(lbase, tab, pk);
+    const uint32_t u1 = PJD_LUT_USED(e), size1 = PJD_LUT_SIZE(e), adv1 = PJD_LUT_ADV(e);
+    const uint32_t u12 = PJD_LUT_PAIR_USED(e), adv12 = PJD_LUT_PAIR_ADV(e), size2 = PJD_LUT_PAIR_SIZE2(e);
+    const bool pair = u12 != 0 && S.zb >= (int)adv1 && S.p + u1 < end_bit;
+    O.npair += pair ? 1u : 0u;
+    // values: `size` bits after the code(s); an invalid entry (size field 14 / 15) yields garbage here and sends the lane to the
+    // careful pass through S.emax
+    const int val1 = jpeg_value(pk, u1, size1);
+    const int val2 = jpeg_value(pk, u12, size2);                            // no pair: zero bits
+    const uint32_t used = pair ? u12 : u1, adv = pair ? adv12 : adv1;
     w.drop(used);
     S.p += used;
-    S.emax = S.emax > e ? S.emax : e;
+    { const uint32_t el = e & 0xffffu; S.emax = S.emax > el ? S.emax : el; }
     S.zb -= (int)adv;
     const bool done = S.zb < 0;
     { const uint32_t u = (uint32_t)(S.zb + 16); S.umin = S.umin < u ? S.umin : u; }      // run past slot 63 (jpeg_scanner.cpp:500): -16..-2 here
-    // entry (layout: pjd_internal.h); the field above the value is the run (advance - 1; an EOB's 64 drops out), or bit 11 of a DC difference
-    const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : ((adv - 1u) & 15u);
-    const uint32_t ent = ((uint32_t)val & 0x7ffu) | (top << 12) | (done ? PJD_ENT_LAST : 0u);
+    // entries (layout: pjd_internal.h): value << 5 | run + 1 (the low five bits of the advance: 0 for an EOB); a DC difference as it is
+    const uint32_t entA = is_dc ? (uint32_t)val1 : (((uint32_t)val1 << 5) | (adv1 & 31u));
+    const uint32_t entB = pair ? (((uint32_t)val2 << 5) | ((adv12 - adv1) & 31u)) : PJD_ENT_NONE;
     // DC sums of this lane, per component (the predictors come from a scan over lanes)
-    const uint32_t dv = is_dc ? ((uint32_t)val & 0xffffu) : 0u;
+    const uint32_t dv = is_dc ? ((uint32_t)val1 & 0xffffu) : 0u;
     const uint32_t dvv = dv | (dv << 16);
     O.dcA = pk_add16(O.dcA, dvv & S.mA);
     O.dcB = pk_add16(O.dcB, dvv & S.mB);
@@ -600,13 +626,13 @@ __device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState
     S.mA = done ? nx.z : S.mA;
     S.mB = done ? nx.w : S.mB;
     D = add_flag(D, done);
-    O.left -= done ? 1u : 0u;
-    return ent;
+    return __builtin_amdgcn_perm(entB, entA, 0x05040100u);                  // low halves of both: A | B << 16
 }
 
 // Decodes from (p, c, z) until end_bit or until the segment's last data unit is complete (D == D_end).
-// Every active lane emits exactly one entry per step, so the entry count is the same in all of them and the
-// staging buffer is flushed by the whole wave at once.
+// Every active lane takes exactly one step per iteration and a step is one word of the staging buffer whether it holds one
+// symbol or two, so the fill is the same in all lanes still decoding: the seven steps of a group are unrolled (their rows of the
+// staging buffer are constants) and the group is flushed by the whole wave at once.
 __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col,
                                            uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                            uint32_t &err, uint32_t &D, uint32_t D_end, OutCtx &O)
@@ -621,22 +647,28 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
     }
     O.stage[0] = z;                                                          // head of group 0: no unit completed yet, the first entry fills from slot z
     O.n = 2;
-    for (;;) {
-        if (S.p >= end_bit || D >= D_end) break;
-        const uint32_t e0 = write_step(P.lbase, w, S, D, O);
-        O.n++;
-        if (S.p >= end_bit || D >= D_end) { O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0; break; }
-        const uint32_t e1 = write_step(P.lbase, w, S, D, O);
-        O.stage[((O.n >> 1) & (PJD_STAGE_ENTRIES / 2 - 1)) * 64] = e0 | (e1 << 16);
-        O.n++;
-        if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {
+    bool running = S.p < end_bit && D < D_end;
+    while (running) {                                                        // one group per iteration
+#pragma unroll
+        for (int k = 1; k < PJD_STAGE_ENTRIES / 2; k++)
+            if (running) {
+                O.stage[k * 64] = write_step(P.lbase, w, S, D, O, end_bit);
+                O.n += 2;
+                running = S.p < end_bit && D < D_end;
+            }
+        if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {                          // the group is full
             stage_flush(O, O.n - PJD_STAGE_ENTRIES);
-            if (O.n + PJD_STAGE_ENTRIES > O.cap) { O.overflow = 1; break; }
-            O.stage[0] = ((D - O.D_in) << 8) | (63u - (uint32_t)S.zb);      // head of the next group: where its first entry stands
-            O.n += 2;
+            if (running) {
+                if (O.n + PJD_STAGE_ENTRIES > O.cap) { O.overflow = 1; running = false; }
+                else {
+                    O.stage[0] = ((D - O.D_in) << 8) | (63u - (uint32_t)S.zb);      // head of the next group: where its first entry stands
+                    O.n += 2;
+                }
+            }
         }
     }
-    if (O.n & (PJD_STAGE_ENTRIES - 1)) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
+    if ((O.n & (PJD_STAGE_ENTRIES - 1)) > 2) stage_flush(O, O.n & ~(uint32_t)(PJD_STAGE_ENTRIES - 1));
+    else if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 2) O.n -= 2;                 // a head without a step behind it is not part of the stream
     err = (S.emax >= (PJD_LUT_BADSYM << 12) || S.umin <= 14u) ? 1u : 0u;
     p = S.p;
     c = P.dus1 - ((S.ra - P.xbase) >> 4);
@@ -649,11 +681,15 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
 // bitstream before the picture is complete.  It stops AT the offending symbol exactly as decode_MCU_component does
 // (reference src/jpeg_scanner.cpp:469-518): nothing of that symbol is stored, everything before it is; an error inside a unit's
 // AC part leaves the unit with what it has (closed here by an end-of-block entry), an error in the DC symbol leaves the unit
-// untouched.  Rare by construction, so entries go straight to HBM two bytes at a time.
+// untouched.  Rare by construction, so every symbol is a step word of its own, written straight to HBM.
 //   eof_rel: bits from the lane's first byte to the end of the stream, or ~0 if the stream does not end in this lane's segment:
 //            running out of bits is get_next_symbol's 0xFF / read_bits' -1 (reference src/headers/jpeg.h:91-113)
 struct Careful {
-    uint32_t n;            // entries written
+    // in: where the lane's marks start (the fast pass wrote them against ITS layout -- pairs share a step word there -- so they are written again)
+    PjdDevMark *marks;
+    uint32_t mark_next, mark_D, ru, lane_q;
+    // out
+    uint32_t n;            // slots written (heads included; two per step word)
     uint32_t cls;          // PJD_ST_* of the error, 0: none found
     uint32_t p_err, D_err, in_dc;
     uint32_t dcA, dcB;
@@ -663,6 +699,7 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
                                           uint32_t end_bit, uint32_t eof_rel, uint32_t D, uint32_t D_end, uint16_t *region, uint32_t cap, Careful &R)
 {
     const uint32_t D_in = D;
+    uint32_t *region32 = reinterpret_cast<uint32_t *>(region);
     BitWin w;
     w.init(wave_words, col, p);
     uint4 cur = lds_u32x4(P.self(P.dus1 - c));      // .x tables, .y own record, .z / .w DC-sum selectors of the current unit
@@ -671,10 +708,16 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
     const bool at_end = eof_rel != 0xffffffffu;
     while (D < D_end && (p < end_bit || at_end)) {
         const bool is_dc = zb == 63;
-        if ((R.n & (PJD_GROUP - 1)) == 0 && R.n + 2 <= cap) {                    // a group begins: its head (pjd_internal.h), two slots
-            const uint32_t h = ((D - D_in) << 8) | (63u - (uint32_t)zb);
-            region[R.n] = (uint16_t)h; region[R.n + 1] = (uint16_t)(h >> 16);
+        if ((R.n & (PJD_GROUP - 1)) == 0 && R.n + 2 <= cap) {                    // a group begins: its head (pjd_internal.h)
+            region32[R.n >> 1] = ((D - D_in) << 8) | (63u - (uint32_t)zb);
             R.n += 2;
+        }
+        if (is_dc && D == R.mark_D) {                                            // this unit opens an IDCT workgroup's range (as write_step)
+            PjdDevMark m;
+            m.lane = R.lane_q; m.ent_off = R.n;
+            m.acc[0] = (uint16_t)R.dcA; m.acc[1] = (uint16_t)(R.dcA >> 16); m.acc[2] = (uint16_t)R.dcB; m.pad_ = 0;
+            R.marks[R.mark_next++] = m;
+            R.mark_D += R.ru;
         }
         const uint32_t pk = w.peek();
         const uint4 nx = lds_u32x4(cur.y);
@@ -694,23 +737,22 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
         }
         if (bad) {
             R.cls = bad; R.p_err = p; R.D_err = D; R.in_dc = is_dc ? 1u : 0u;
-            if (!is_dc && R.n < cap) region[R.n++] = (uint16_t)PJD_ENT_LAST;       // the unit keeps what it has (its group head, if it opens a group, was written above)
+            if (!is_dc && R.n + 2 <= cap) { region32[R.n >> 1] = PJD_ENT_EOB | (PJD_ENT_NONE << 16); R.n += 2; }   // the unit keeps what it has (its group head, if it opens a group, was written above)
             break;
         }
-        const uint32_t bits = __builtin_amdgcn_ubfe(pk, 32u - used, size);
-        const uint32_t m1 = 1u << size;
-        const int val = (int)bits + ((((int)bits - (int)(m1 >> 1)) >> 31) & (int)(1u - m1));
+        const int val = jpeg_extend(__builtin_amdgcn_ubfe(pk, 32u - used, size), size);
         w.drop(used);
         p += used;
         zb -= (int)adv;
         const bool done = zb < 0;
-        const uint32_t top = is_dc ? (((uint32_t)val >> 11) & 1u) : ((adv - 1u) & 15u);
-        if (R.n < cap) region[R.n++] = (uint16_t)(((uint32_t)val & 0x7ffu) | (top << 12) | (done ? PJD_ENT_LAST : 0u));
+        const uint32_t ent = is_dc ? ((uint32_t)val & 0xffffu) : ((((uint32_t)val << 5) | (adv & 31u)) & 0xffffu);
+        if (R.n + 2 <= cap) { region32[R.n >> 1] = ent | (PJD_ENT_NONE << 16); R.n += 2; }
         const uint32_t dv = is_dc ? ((uint32_t)val & 0xffffu) : 0u, dvv = dv | (dv << 16);
         R.dcA = pk_add16(R.dcA, dvv & cur.z);
         R.dcB = pk_add16(R.dcB, dvv & cur.w);
         if (done) { zb = 63; cur = nx; D++; }
     }
+    if ((R.n & (PJD_GROUP - 1)) == 2) R.n -= 2;                                  // a head without a step behind it
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1083,6 +1125,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     // ---- W: write pass from the true entry states
     const uint32_t prev_p = __shfl_up(S.p_img, 1), prev_cz = __shfl_up(S.cz, 1);
     const uint32_t prev_v = __shfl_up(v, 1), prev_f = __shfl_up(f, 1);      // inclusive counts of the lane before: this lane's first unit
+    uint32_t npair = 0;                                  // steps of this lane's write pass that held a symbol pair
     PjdDevLaneInfo li;
     li.n_ent = 0; li.first_du = g.seg_first ? PJD_LANE_SEG_FIRST : 0u; li.dc_sum[0] = li.dc_sum[1] = li.dc_sum[2] = 0; li.pad_ = 0;
     if (g.valid && !dead) {
@@ -1103,10 +1146,10 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         }
         if (D_in < D_end && !flag) {
             OutCtx O;
-            O.region = B.ent + (size_t)g.q * B.lane_cap;
+            O.region = B.ent + im.ent_base + (size_t)(g.q - im.lane_base) * im.lane_cap;
             O.stage = area + l;
-            O.cap = B.lane_cap;
-            O.n = 0; O.dcA = 0; O.dcB = 0; O.overflow = 0;
+            O.cap = im.lane_cap;
+            O.n = 0; O.npair = 0; O.dcA = 0; O.dcB = 0; O.overflow = 0;
             O.ru = im.idct_mcus * dus;
             O.marks = B.marks + im.iwg_base;
             O.lane_q = g.q;
@@ -1117,12 +1160,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 const uint32_t d_next = (z == 0) ? D_in : D_in + 1;                       // first unit starting here
                 const uint32_t k = (d_next - first_du + O.ru - 1) / O.ru;                 // ranges are [first_du + k * ru, ...)
                 O.mark_next = k;
-                O.left = first_du + k * O.ru - D_in;
+                O.mark_D = first_du + k * O.ru;
             }
             uint32_t err = 0;
-            const uint32_t p0 = p, c0 = c, z0 = z;
+            const uint32_t p0 = p, c0 = c, z0 = z, mark_next0 = O.mark_next, mark_D0 = O.mark_D;
             write_span(P, g.words, g.col, p, c, z, g.end_bit, err, D, D_end, O);
             li.n_ent = O.n;
+            npair = O.npair;
             li.dc_sum[0] = (uint16_t)O.dcA; li.dc_sum[1] = (uint16_t)(O.dcA >> 16); li.dc_sum[2] = (uint16_t)O.dcB;
             const bool has_next = g.seg + 1 < im.seg_base + im.n_seg;
             // the lane in which the bitstream ends: too few bits for the picture is the reference's end-of-data error, not ours
@@ -1132,10 +1176,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
                 // an entropy-coding error of the TRUE decode (this lane started from the true state): find it exactly, keep what
                 // precedes it, report it by position -- the picture's verdict takes the first one (pjd_k_image_verdict)
                 Careful R;
+                R.marks = O.marks; R.mark_next = mark_next0; R.mark_D = mark_D0; R.ru = O.ru; R.lane_q = g.q;
                 careful_span(P, g.words, g.col, p0, c0, z0, g.end_bit, eof_lane ? g.seg_end_bit : 0xffffffffu, D_in, D_end, O.region, O.cap, R);
+                // the region and the lane's marks now have the careful pass's layout (one symbol per step word), error or not
+                li.n_ent = R.n;
+                npair = 0;
+                li.dc_sum[0] = (uint16_t)R.dcA; li.dc_sum[1] = (uint16_t)(R.dcA >> 16); li.dc_sum[2] = (uint16_t)R.dcB;
                 if (R.cls) {
-                    li.n_ent = R.n;
-                    li.dc_sum[0] = (uint16_t)R.dcA; li.dc_sum[1] = (uint16_t)(R.dcA >> 16); li.dc_sum[2] = (uint16_t)R.dcB;
                     const unsigned long long key = ((unsigned long long)(g.base_bit + R.p_err) << 32) | ((unsigned long long)R.D_err << 4) | (R.cls << 1) | R.in_dc;
                     atomicMin(&B.imstate[hw.image].err_key, key);
                     settled = true;
@@ -1173,13 +1220,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     // flagged lane; conditions that concern the whole wave flag every lane, i.e. the wave's first).  Whether that sends the picture
     // to the exact kernel is decided per picture once all its waves have reported (pjd_k_image_verdict): what lies behind the
     // picture's first entropy-coding error is never decoded by the reference and does not count.
-    uint32_t wflag = flag, went = g.valid ? li.n_ent - 2u * ((li.n_ent + PJD_GROUP - 1) / PJD_GROUP) : 0, wpos = (flag && g.valid) ? g.base_bit : 0xffffffffu;
+    uint32_t wflag = flag, went = npair, wsteps = g.valid ? li.n_ent / 2 - (li.n_ent + PJD_GROUP - 1) / PJD_GROUP : 0, wpos = (flag && g.valid) ? g.base_bit : 0xffffffffu;
     for (int off = 1; off < 64; off <<= 1) {
-        wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off);
+        wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off); wsteps += __shfl_xor(wsteps, off);
         const uint32_t o = __shfl_xor(wpos, off);
         wpos = o < wpos ? o : wpos;
     }
-    if (l == 0) atomicAdd(B.stats + PJD_STAT_ENTRIES, (unsigned long long)went);
+    if (l == 0) { atomicAdd(B.stats + PJD_STAT_ENTRIES, (unsigned long long)(went + wsteps)); atomicAdd(B.stats + PJD_STAT_STEPS, (unsigned long long)wsteps); }
     if (wflag && l == 0) {
         atomicMin(&B.imstate[hw.image].flag_pos, wpos);
         for (int r = 0; r < PJD_FLAG_REASONS; r++)

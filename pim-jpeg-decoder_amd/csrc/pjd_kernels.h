@@ -21,7 +21,7 @@ struct PjdDevBatch {
     const uint8_t *ecs;
     uint32_t *words;                     // transposed bitstream words: [wave][PJD_WORD_ROWS][64]
     int16_t *coef;                       // DENSE scratch (exact-kernel path): dense_du * 64 int16, zigzag-slot order
-    uint16_t *ent;                       // lane streams: lane q owns entries [q * lane_cap, (q + 1) * lane_cap)
+    uint16_t *ent;                       // lane streams: lane q of image `im` owns slots [im.ent_base + (q - im.lane_base) * im.lane_cap, + im.lane_cap)
     PjdDevLaneInfo *lane_info;           // per lane
     PjdDevLaneDc *lane_dc;               // per lane
     uint16_t *dc_blk;                    // per DC scan block: aggregate {Y, Cb, Cr, has_head}, then carry-in {Y, Cb, Cr, -}
@@ -39,7 +39,7 @@ struct PjdDevBatch {
     uint32_t n_images, n_tsets, n_lanes, n_hwave, n_hwg, n_iwg, n_dcblk;
     uint32_t sub_bytes;                  // Huffman subsequence size of this batch
     uint32_t word_rows;                  // PJD_WORD_ROWS(sub_bytes)
-    uint32_t lane_cap;                   // PJD_LANE_CAP(sub_bytes)
+    uint32_t lane_cap;                   // largest PjdDevImage::lane_cap of the batch (diagnostics)
     uint32_t max_lut_bytes;              // largest PjdDevTset::lut_bytes in the batch (sizes the dynamic LDS of the Huffman kernel)
 };
 

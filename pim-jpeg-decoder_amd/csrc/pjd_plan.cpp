@@ -78,11 +78,16 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         P.sub_bytes = sb;
     }
     const uint32_t SB = P.sub_bytes;
+    // experiments: one walker threshold for every picture of the plan (pjd_internal.h); read once per plan
+    int walk_max_env = -1;
+    if (const char *e = std::getenv("PJD_WALK_MAX")) { const int v = std::atoi(e); walk_max_env = v < 0 ? 0 : v; }
 
     uint64_t ecs_off = 0, out_off = 0, du_total = 0, dense_seq = 0, lut_off = 0;
     uint32_t sb_max = SB;                          // largest per-image subsequence: sizes the word rows and the lane regions
     std::map<std::string, uint32_t> tset_of;       // raw bytes of a deduplicated table list -> table set
     std::vector<char> tset_parallel;               // per set: the two-level tables fit the parallel decoder
+    std::vector<uint32_t> tset_min_bits;           // per set: fewest bits (code + value bits) any of its symbols consumes
+    uint64_t ent_off = 0;                          // slots of the lane regions handed out so far
     for (int i = 0; i < n; i++) {
         const pjd_image_desc &d = images[i];
         PjdDevImage &g = P.images[i];
@@ -193,6 +198,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             // 9-bit prefix that holds codes longer than 9 bits.  Over-subscribed tables (not a prefix code) and
             // tables whose long codes need more LDS than PJD_LUT_LDS_MAX go to the exact kernel.
             bool ok = true;
+            uint32_t set_min_bits = 16;
             uint32_t lut_bytes = (uint32_t)nt * PJD_L1_BYTES;
             for (int k = 0; k < nt; k++) {
                 PjdDevHuffRaw &r = P.tables[(size_t)ts * PJD_MAX_TABLES + k];
@@ -206,6 +212,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                     for (uint32_t q = r.offsets[len - 1]; q < r.offsets[len] && q < 162; q++) {
                         const uint32_t sym = r.symbols[q], size = seen_ac[k] ? ((sym & 15u) > 10 ? 0u : (sym & 15u)) : (sym > 11 ? 0u : sym);
                         if ((uint32_t)len + size < P.min_sym_bits) P.min_sym_bits = (uint32_t)len + size;
+                        if ((uint32_t)len + size < set_min_bits) set_min_bits = (uint32_t)len + size;
                     }
                     if (code + cnt > (1u << len)) ok = false;
                     if (len == PJD_LUT_BITS) end10 = code + cnt;
@@ -227,6 +234,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             if (T.lut_bytes > P.max_lut_bytes) P.max_lut_bytes = T.lut_bytes;
             P.tsets.push_back(T);
             tset_parallel.push_back(ok ? 1 : 0);
+            tset_min_bits.push_back(set_min_bits < 1 ? 1u : set_min_bits);
         }
         g.tset = progressive ? 0u : found->second;
         const bool tables_parallel_ok = !progressive && tset_parallel[g.tset] != 0;
@@ -325,11 +333,12 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         }
         g.sub_bytes = SBi;
         {   // which re-sync rounds the wave walks (pjd_internal.h)
-            const uint64_t n_mcu_img = (uint64_t)g.mcux * g.mcuy ? (uint64_t)g.mcux * g.mcuy : 1;
-            const uint64_t bpm = d.ecs_len / n_mcu_img;                                   // bytes of stream per MCU, whole picture
+            // density of what THIS image (or shard: a slice of the stream for a slice of the MCUs) decodes
+            const uint64_t n_mcu_dec = g.last_mcu > g.first_mcu ? g.last_mcu - g.first_mcu : 1;
+            const uint64_t bpm = (byte_hi - byte_lo) / n_mcu_dec;                         // bytes of stream per MCU
             uint32_t wm = SBi >> PJD_WALK_SHIFT;
             if ((uint64_t)SBi <= PJD_WALK_DENSE_MCUS * bpm && wm < PJD_WALK_DENSE) wm = PJD_WALK_DENSE;
-            if (const char *e = std::getenv("PJD_WALK_MAX")) { const int v = std::atoi(e); wm = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
+            if (walk_max_env >= 0) wm = (uint32_t)(walk_max_env > 64 ? 64 : walk_max_env);
             g.walk_max = (uint8_t)wm;
         }
         if (SBi > sb_max) sb_max = SBi;
@@ -357,6 +366,11 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             }
             g.n_seg = (uint32_t)P.segs.size() - g.seg_base;
             g.n_lane = (uint32_t)P.subs.size() - g.lane_base;
+            // lane regions of this picture: sized by ITS subsequence and the cheapest symbol of ITS tables (pjd_internal.h)
+            g.lane_cap = PJD_LANE_CAP(SBi, tset_min_bits[g.tset]);
+            g.ent_base = ent_off;
+            ent_off += (uint64_t)g.n_lane * g.lane_cap;
+            if (g.lane_cap > P.lane_cap) P.lane_cap = g.lane_cap;
             for (uint32_t s0 = 0; s0 < g.n_lane; s0 += PJD_HUFF_LANES) {
                 PjdDevHuffWave w;
                 w.image = (uint32_t)i;
@@ -430,8 +444,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     P.n_du = du_total;
     P.sub_bytes = sb_max;
     if (P.min_sym_bits < 1 || P.tsets.empty()) P.min_sym_bits = 1;
-    P.lane_cap = PJD_LANE_CAP(sb_max, P.min_sym_bits);
-    P.n_ent = (uint64_t)P.subs.size() * P.lane_cap + 16;
+    P.n_ent = ent_off + 16;
     P.n_words = (uint64_t)P.hwaves.size() * PJD_WORD_ROWS(sb_max) * 64;
     P.dense_du = dense_seq;
     P.out_buf_bytes = align_up(out_off, 256);

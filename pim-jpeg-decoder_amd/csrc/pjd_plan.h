@@ -22,7 +22,7 @@ struct PjdPlan {
     int out_format = 0;
     uint32_t sub_bytes = 512;              // Huffman subsequence size chosen for this batch
     uint32_t min_sym_bits = 16;            // fewest bits any Huffman symbol of the batch's tables consumes (code + value bits)
-    uint32_t lane_cap = 0;                 // entries per lane region: PJD_LANE_CAP(sub_bytes, min_sym_bits)
+    uint32_t lane_cap = 0;                 // slots of the largest lane region of the batch (a picture's own: PjdDevImage::lane_cap)
     std::vector<PjdDevImage> images;
     std::vector<PjdHostImage> host;
     std::vector<PjdDevTset> tsets;         // table sets: images with identical Huffman tables share one
@@ -40,7 +40,7 @@ struct PjdPlan {
     std::vector<uint32_t> fast_images;     // the others
     uint64_t ecs_buf_bytes = 0;            // size of the packed bitstream buffer (incl. padding)
     uint64_t n_du = 0;                     // data units in the batch
-    uint64_t n_ent = 0;                    // capacity of the lane streams (16-bit entries): lanes * PJD_LANE_CAP
+    uint64_t n_ent = 0;                    // capacity of the lane streams in 16-bit slots: sum over pictures of lanes * PjdDevImage::lane_cap
     uint64_t n_words = 0;                  // transposed bitstream words: waves * PJD_WORD_ROWS * 64
     uint64_t dense_du = 0;                 // data units of the dense scratch (exact-kernel images + one fallback image)
     uint64_t out_buf_bytes = 0;

@@ -276,6 +276,8 @@ int pjd_split_decode(const pjd_image_desc *desc, const int32_t *devices, int n_d
     if (he == hipSuccess) { hipSetDevice(devices[0]); he = hipMemcpyAsync(d_blob[0], blob.data(), blob_bytes, hipMemcpyHostToDevice, (hipStream_t)pjd_stream(ctx[0])); }
     bool by_rccl = false;
     if (he == hipSuccess && distinct && rccl().ok && !std::getenv("PJD_SPLIT_NO_RCCL")) {
+        // One collective at a time per process: the communicators are cached per device list, and creating them (ncclCommInitAll, about
+        // a second) happens under this lock -- concurrent pjd_split_decode callers are serialised through this leg.
         std::lock_guard<std::mutex> l(g_comm_m);
         std::vector<int> devs(devices, devices + world);
         if (g_comm_devs != devs) {
@@ -285,26 +287,36 @@ int pjd_split_decode(const pjd_image_desc *desc, const int32_t *devices, int n_d
             else { g_comms.clear(); }
         }
         if (!g_comms.empty()) {
-            int nr = rccl().GroupStart();
+            const bool open = rccl().GroupStart() == 0;            // a group that did not open is not closed either
+            int nr = open ? 0 : -1;
             for (int r = 0; r < world && nr == 0; r++) {
-                hipSetDevice(devices[r]);
+                if (hipSetDevice(devices[r]) != hipSuccess) { nr = -1; break; }
                 nr = rccl().Broadcast(d_blob[0], d_blob[(size_t)r], blob_bytes, kNcclUint8, 0, g_comms[(size_t)r], (hipStream_t)pjd_stream(ctx[(size_t)r]));
             }
-            const int ne = rccl().GroupEnd();
+            const int ne = open ? rccl().GroupEnd() : -1;
             by_rccl = nr == 0 && ne == 0;
-            if (!by_rccl) drop_comms_locked();
+            if (!by_rccl) {
+                // Part of the group may have reached the streams: drain them and drop the communicators BEFORE the plain copies below
+                // reuse the same streams and buffers.
+                for (int r = 0; r < world; r++)
+                    if (hipSetDevice(devices[r]) == hipSuccess) (void)hipStreamSynchronize((hipStream_t)pjd_stream(ctx[(size_t)r]));
+                (void)hipGetLastError();
+                drop_comms_locked();
+                if (hipSetDevice(devices[0]) == hipSuccess)         // rank 0's copy of the blob may not have survived an aborted group
+                    he = hipMemcpyAsync(d_blob[0], blob.data(), blob_bytes, hipMemcpyHostToDevice, (hipStream_t)pjd_stream(ctx[0]));
+            }
         }
     }
     if (he == hipSuccess && !by_rccl) {
         // no collective available (RCCL missing, or ranks that share a device in a test): the same bytes by plain copies
         for (int r = 1; r < world && he == hipSuccess; r++) {
-            hipSetDevice(devices[r]);
-            he = hipMemcpyAsync(d_blob[(size_t)r], blob.data(), blob_bytes, hipMemcpyHostToDevice, (hipStream_t)pjd_stream(ctx[(size_t)r]));
+            he = hipSetDevice(devices[r]);
+            if (he == hipSuccess) he = hipMemcpyAsync(d_blob[(size_t)r], blob.data(), blob_bytes, hipMemcpyHostToDevice, (hipStream_t)pjd_stream(ctx[(size_t)r]));
         }
     }
     for (int r = 0; r < world && he == hipSuccess; r++) {           // every rank reads back what IT received
-        hipSetDevice(devices[r]);
-        he = hipMemcpyAsync(got[(size_t)r].data(), d_blob[(size_t)r], blob_bytes, hipMemcpyDeviceToHost, (hipStream_t)pjd_stream(ctx[(size_t)r]));
+        he = hipSetDevice(devices[r]);
+        if (he == hipSuccess) he = hipMemcpyAsync(got[(size_t)r].data(), d_blob[(size_t)r], blob_bytes, hipMemcpyDeviceToHost, (hipStream_t)pjd_stream(ctx[(size_t)r]));
         if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)pjd_stream(ctx[(size_t)r]));
     }
     free_blobs();

@@ -19,7 +19,7 @@ OUT_RGB8, OUT_BMP = 0, 1
 F_STANDARD_RESTART, F_FORCE_SEQUENTIAL, F_STANDARD_ZIGZAG, F_PROGRESSIVE = 1, 2, 4, 8
 SCAN_PROGRESSIVE = 1
 MAX_KERNELS = 16
-ABI_VERSION = 4          # PJD_VERSION of include/pjd.h these ctypes structs mirror
+ABI_VERSION = 5          # PJD_VERSION of include/pjd.h these ctypes structs mirror
 
 
 class HuffTable(C.Structure):
@@ -67,7 +67,7 @@ class BatchInfo(C.Structure):
                 ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64),
                 ("sub_bytes", C.c_uint32), ("n_table_sets", C.c_uint32), ("n_huff_waves", C.c_uint64),
                 ("n_entries", C.c_uint64), ("exact_fallback_ms", C.c_float), ("n_entropy_errors", C.c_uint32),
-                ("flag_waves", C.c_uint64 * 8), ("huff_lds_bytes", C.c_uint32), ("reserved_", C.c_uint32), ("walks", C.c_uint64), ("walk_lanes", C.c_uint64)]
+                ("flag_waves", C.c_uint64 * 8), ("huff_lds_bytes", C.c_uint32), ("reserved_", C.c_uint32), ("walks", C.c_uint64), ("walk_lanes", C.c_uint64), ("n_steps", C.c_uint64)]
 
 
 SPLIT_MAX_DEVICES = 16

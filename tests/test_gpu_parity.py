@@ -1083,6 +1083,54 @@ def test_corrupt_and_truncated_4k_pictures_settle_on_the_parallel_path(ctx, port
     assert n_err >= 2          # the cut always ends in the reference's end-of-data error; the overwrite may re-synchronise cleanly
 
 
+def test_error_in_a_unit_that_runs_on_into_the_next_lane(port, monkeypatch):
+    """An entropy-coding error in a unit's AC part, a few bytes before a subsequence boundary: the reference stops there and the
+    unit keeps what it had (src/jpeg_scanner.cpp:490,506).  The lane BEHIND the boundary was synchronised as if the stream went
+    on, starts inside that very unit, and its leading AC entries must not reach the picture (round-3 review: the group parser of
+    the back end took them, because the erring unit counts as decoded).  16 one-bits (no table assigns that code) are planted
+    2 and 5 bytes before every boundary of a dense picture cut into 128-byte subsequences; status, pixels and coefficients
+    equal the oracle's for every one of them."""
+    import pjd_amd
+    synth = _synth()
+    monkeypatch.setenv("PJD_SUB_BYTES", "128")
+    good = synth.make(200, 152, 77, 95, synth.SUB_420, 0, synth.DENSE_DETAIL, True)
+    body = good.rfind(b"\xff\xda") + 14
+    end = len(good) - 2
+    file_pos, i = [], body                    # file offset of every destuffed byte of the entropy-coded segment
+    while i < end:
+        file_pos.append(i)
+        i += 2 if good[i] == 0xFF else 1
+    jpegs = []
+    for k in range(1, len(file_pos) // 128):
+        for r in (2, 5):
+            f = file_pos[k * 128 - r - 2]
+            if 0xFF in good[f - 1:f + 5]:
+                continue
+            jpegs.append(good[:f] + b"\xff\x00\xff\x00" + good[f + 4:])
+    assert len(jpegs) > 200
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    assert all(s.valid for s in scanned)
+    c = pjd_amd.Context(0)
+    try:
+        with c.batch([s.desc for s in scanned]) as b:
+            b.upload(); b.decode(); b.sync()
+            outs, st = b.download()
+            info = b.info()
+            assert info["sub_bytes"] == 128
+            n_ac = 0
+            for i, j in enumerate(jpegs):
+                want = port.decode(j)
+                assert st[i] == want["huff_rc"], (i, st[i], want["huff_rc"])
+                assert np.array_equal(outs[i], want["rgb"]), i
+                if i % 4 == 0:
+                    assert np.array_equal(b.coefficients(i), want["coef"]), i
+                n_ac += st[i] in (4, 6)              # PJD_ST_AC_SYM / PJD_ST_AC_LEN: the unit stays open at the error
+            assert n_ac > 150
+            assert info["n_sequential"] == 0 and info["n_fallback"] == 0, info["flag_waves"]
+    finally:
+        c.close()
+
+
 # ---- progressive frames (SURVEY 8f N4): not reference-comparable, PARITY UNPINNED ----------------------------------------------
 def test_progressive_decodes_to_the_baseline_twin(ctx, port):
     """The reference cannot decode progressive files (its scanner rejects them, src/jpeg_scanner.cpp:425-430), so nothing of

@@ -20,7 +20,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _tall_picture():
+    """64 x 16384, 4:4:4, one restart interval per MCU row: 2,048 restart segments like BASELINE config 5's 16384 x 16384 picture
+    (whose descriptor has the same shape: 2,048 offsets), at 1/256 of its pixels."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    return synth.make(64, 16384, 5, 85, synth.SUB_444, 8)
+
+
+def _worker(rank, world, port, ret, which="fixture"):
     sys.path.insert(0, os.path.join(ROOT, "pim-jpeg-decoder_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -30,17 +38,21 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        data = golden_bytes("rstrow_200x150_444_opt")
         # the code path of bench.py --workload cfg5split: rank 0 scans, one descriptor broadcast, bitstream slices scattered
+        data = (golden_bytes("rstrow_200x150_444_opt") if which == "fixture" else _tall_picture()) if rank == 0 or which == "fixture" else None
         s = pjd_amd.Scanned(data) if rank == 0 else None
         d, keep, blob_bytes = parallel.distribute_image(s, src=0)
         sl, segs = keep
         desc = d
-        lo = int(pjd_amd.Scanned(data).seg_offsets()[d.shard_first_seg])
         info = pjd_amd.plan_info([d])
-        ret[rank] = {"w": int(desc.width), "h": int(desc.height), "nseg": int(desc.n_segments), "first": int(d.shard_first_seg),
-                     "count": int(d.shard_n_segs), "slice": len(sl), "lo": int(lo), "subs": info["n_subsequences"],
-                     "seq": info["n_sequential"], "sha": __import__("hashlib").sha256(sl.tobytes()).hexdigest()}
+        out = {"w": int(desc.width), "h": int(desc.height), "nseg": int(desc.n_segments), "first": int(d.shard_first_seg),
+                     "count": int(d.shard_n_segs), "slice": len(sl), "subs": info["n_subsequences"], "ri": int(desc.restart_interval),
+                     "seq": info["n_sequential"], "sha": __import__("hashlib").sha256(sl.tobytes()).hexdigest(), "blob": int(blob_bytes),
+                     "own_first_off": int(segs[d.shard_first_seg]), "own_last_off": int(segs[d.shard_first_seg + d.shard_n_segs - 1]),
+                     "world": dist.get_world_size()}
+        if which == "fixture":
+            out["lo"] = int(pjd_amd.Scanned(data).seg_offsets()[d.shard_first_seg])
+        ret[rank] = out
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -63,6 +75,39 @@ def test_two_rank_descriptor_broadcast_and_scatter():
     assert ret[0]["sha"] == hashlib.sha256(ecs[:cut].tobytes()).hexdigest()
     assert ret[1]["sha"] == hashlib.sha256(ecs[cut:].tobytes()).hexdigest()
     assert ret[0]["seq"] == 0 and ret[1]["seq"] == 0 and ret[0]["subs"] > 0 and ret[1]["subs"] > 0
+
+
+def test_eight_ranks_tile_a_2048_segment_picture_once():
+    """World size 8 (gloo) through parallel.distribute_image -- what `bench.py --gpus 8 --workload cfg5split` runs over RCCL -- on a
+    picture with 2,048 restart segments (BASELINE config 5's count): every rank gets 256 consecutive segments, the slices are the
+    scanned bitstream cut at segment boundaries (each byte exactly once, in order), every shard's own offsets start at 0, and the
+    MCU ranges they stand for tile the picture once.  Reference: one picture over every allocated DPU, src/decoder_host.cpp:125-149,262-312."""
+    import hashlib
+    import pjd_amd
+    world, port = 8, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, "tall"), nprocs=world, join=True)
+    s = pjd_amd.Scanned(_tall_picture())
+    segs, ecs = s.seg_offsets(), s.ecs()
+    assert len(segs) == 2048 and s.desc.restart_interval == 8
+    n_mcu = 8 * 2048
+    next_seg, next_byte, next_mcu = 0, 0, 0
+    for r in range(world):
+        g = ret[r]
+        assert g["world"] == 8 and (g["w"], g["h"], g["nseg"], g["ri"]) == (64, 16384, 2048, 8)
+        assert (g["first"], g["count"]) == (next_seg, 256)
+        lo = int(segs[g["first"]])
+        hi = int(segs[g["first"] + g["count"]]) if g["first"] + g["count"] < 2048 else len(ecs)
+        assert lo == next_byte and g["slice"] == hi - lo
+        assert g["sha"] == hashlib.sha256(ecs[lo:hi].tobytes()).hexdigest()
+        assert g["own_first_off"] == 0 and g["own_last_off"] == int(segs[g["first"] + g["count"] - 1]) - lo
+        m0, m1 = g["first"] * 8, min((g["first"] + g["count"]) * 8, n_mcu)
+        assert m0 == next_mcu
+        assert g["seq"] == 0 and g["subs"] >= 256          # at least a lane per restart segment, nothing routed to the exact kernel
+        assert g["blob"] == ret[0]["blob"] > 2048 * 8
+        next_seg, next_byte, next_mcu = g["first"] + g["count"], hi, m1
+    assert (next_seg, next_byte, next_mcu) == (2048, len(ecs), n_mcu)
 
 
 def test_more_ranks_than_segments_leaves_ranks_idle():
