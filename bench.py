@@ -144,6 +144,93 @@ def cpu_baseline(jpegs, budget_s=12.0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def cli_end_to_end(jpegs, device):
+    """The drop-in path file to file: `bin/decoder --pipeline` over the SAME JPEGs as files in a tmpfs directory, BMP files written
+    next to them -- the reference's own figure of merit is its "End-to-end execution time" over files (src/decoder_host.cpp:379-394).
+    A child process (it pays process start, HIP initialisation and pool warm-up like any CLI run), timed by its own "Profiles:" block."""
+    import hashlib
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "bin", "decoder")
+    if not os.path.exists(exe):
+        return {"error": "bin/decoder is not built"}
+    tmp = tempfile.mkdtemp(prefix="pjd_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        names = []
+        for k, data in enumerate(jpegs):
+            names.append(os.path.join(tmp, f"{k:05d}.jpg"))
+            with open(names[-1], "wb") as f:
+                f.write(data)
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "--pipeline", "--device", str(device)] + names, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        rows, pixels, pictures = {}, None, None
+        for line in p.stdout.splitlines():
+            line = line.strip()
+            if line.startswith("End-to-end execution time:"):
+                rows["end_to_end_s"] = float(line.split(":")[1].strip().rstrip("s"))
+            elif line.startswith("- ") and "time:" in line:
+                k, v = line[2:].split(":")
+                rows[k.strip().replace(" ", "_").replace("-", "_")] = float(v.strip().rstrip("s"))
+            elif line.startswith("- Total"):
+                w = line.split()
+                pictures, pixels = int(w[4]), float(w[6]) * 1e6          # "- Total <calls> calls, <pictures> pictures, <MPixels> MPixels"
+        n_bmp = sum(1 for k in range(len(jpegs)) if os.path.exists(os.path.join(tmp, f"{k:05d}.bmp")))
+        out = {"returncode": p.returncode, "files": len(jpegs), "bmp_files_written": n_bmp, "process_wall_s": round(wall, 3), "profiles": rows}
+        if "end_to_end_s" in rows and pixels:
+            out.update(value=round(pixels / rows["end_to_end_s"] / 1e6, 2), unit="MPix/s", pictures=pictures,
+                       note="JPEG files on tmpfs -> BMP files on tmpfs through bin/decoder --pipeline (scan | H2D | kernels | D2H | write overlapped); "
+                            "value = pixels / the CLI's own End-to-end execution time, process start and HIP initialisation excluded (process_wall_s has them)")
+            # one picture checked by content: the BMP file equals what this library decodes in memory (the oracle pins that in tests/)
+            k = 0
+            import pjd_amd
+            sc = pjd_amd.Scanned(jpegs[k])
+            ctx = pjd_amd.Context(device)
+            outs, _ = ctx.decode([sc.desc], pjd_amd.OUT_BMP)
+            ctx.close()
+            bmp = open(os.path.join(tmp, f"{k:05d}.bmp"), "rb").read() if n_bmp else b""
+            out["first_bmp_identical_to_library_decode"] = hashlib.sha256(bmp).hexdigest() == hashlib.sha256(bytes(outs[0])).hexdigest()
+        else:
+            out["error"] = (p.stdout[-300:] + p.stderr[-300:])
+        return out
+    except Exception as e:          # never lose the bench line over this extra
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cxx_split_child(tile, seed, devices):
+    """pjd_split_decode (the C++ path: one host thread per device, ONE ncclBroadcast of the descriptor) over `devices` in a child
+    process with a time limit, compared with the one-device decode.  Evidence for BASELINE config 5 at N > 1; never `value`."""
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, json, hashlib
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, pjd_amd, synth
+        data = synth.cfg5_tile(%d, seed=%d)
+        sc = pjd_amd.Scanned(data)
+        devs = %r
+        got, status, stats = pjd_amd.split_decode(sc.desc, devs, pjd_amd.OUT_BMP)
+        got2, status2, stats2 = pjd_amd.split_decode(sc.desc, devs, pjd_amd.OUT_BMP)      # communicators cached: the steady state
+        ctx = pjd_amd.Context(devs[0])
+        whole, st = ctx.decode([sc.desc], pjd_amd.OUT_BMP)
+        ctx.close()
+        same = hashlib.sha256(np.asarray(got2).tobytes()).hexdigest() == hashlib.sha256(np.asarray(whole[0]).tobytes()).hexdigest()
+        keep = ("wall_s", "broadcast_s", "upload_s", "exec_s", "download_s", "blob_bytes", "n_segments", "n_ranks", "n_exact", "rccl_used", "redone_whole")
+        print("RESULT " + json.dumps({"status": int(status2), "equals_one_device_decode": bool(same), "first_call": {k: stats[k] for k in keep},
+                                      "second_call": {k: stats2[k] for k in keep}, "pixels": int(sc.desc.width) * int(sc.desc.height)}))
+    """) % (os.path.join(ROOT, "pim-jpeg-decoder_amd", "python"), os.path.join(ROOT, "tools"), tile, seed, list(devices))
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=420)
+        for line in p.stdout.splitlines():
+            if line.startswith("RESULT "):
+                return json.loads(line[7:])
+        return {"error": (p.stdout[-200:] + p.stderr[-300:]), "returncode": p.returncode}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +250,7 @@ def main():
     ap.add_argument("--out-format", default="bmp", choices=["bmp", "rgb8"],
                     help="what the device writes per picture: the BMP file image the reference's writer would emit (default), or tight RGB8")
     ap.add_argument("--verify", action="store_true", help="check a few pictures against the oracle after the run")
+    ap.add_argument("--no-cli", action="store_true", help="skip cli_end_to_end (bin/decoder --pipeline over the workload as files on tmpfs)")
     ap.add_argument("--e2e-batches", type=int, default=32,
                     help="also run the pipelined batcher (JPEG bytes in host memory -> BMP bytes in pinned host memory, "
                          "PCIe both ways) over this many batches of the workload; 0 = skip.  Reported as pcie_inclusive, never as value")
@@ -191,6 +279,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    # how many ranks the collective backend really joins: one all-reduce of a 1 per rank (RCCL over xGMI with the nccl backend)
+    comm = {"backend": None, "ranks": 1}
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        comm = {"backend": dist.get_backend(), "ranks": int(t.item())}
 
     import pjd_amd
     out_fmt = pjd_amd.OUT_BMP if args.out_format == "bmp" else pjd_amd.OUT_RGB8
@@ -237,6 +331,8 @@ def main():
             descs = [d] if d is not None else []
             label = label or f"one {args.tile}x{args.tile} 4:4:4 q85 JPEG, restart interval = one MCU row"
             label += f"; split by restart segment over {world} ranks (descriptor blob {blob_bytes} B broadcast)"
+            split_info = {"blob_bytes": int(blob_bytes), "rank0_segments": int(d.shard_n_segs) if d is not None else 0,
+                          "rank0_slice_bytes": int(len(keep[0])) if keep is not None else 0, "collective_backend": dist.get_backend()}
         else:
             descs = [s.desc for s in scanned]
         if args.force_exact:
@@ -276,6 +372,7 @@ def main():
              "scan": round(t_scan * 1e3, 1), "upload": round(t_up * 1e3, 1)}}
         if split:
             r["host_ms"]["distribute"] = round(t_dist * 1e3, 1)
+            r["split_info"] = split_info
         # the same K steps strictly one after the other (reported beside `value`, never instead of it)
         if nfl > 1:
             barrier()
@@ -341,6 +438,11 @@ def main():
         # the lighter round-1 set, same run (Annex-K tables shared by every picture, 0.32 B/px)
         V = measure("cfg3lite", max(5, args.steps // 2), args.warmup, False)
         variants["cfg3lite"] = dict(rates(V), workload=V["label"])
+        if world > 1:
+            # BASELINE config 5 beside the batches: ONE picture split by restart segment over the ranks -- the descriptor broadcast and
+            # the slices travel through the process group (RCCL).  Strong scaling; never `value` of this line.
+            S = measure("cfg5split", max(5, args.steps // 4), args.warmup, False)
+            variants["cfg5split"] = dict(rates(S), workload=S["label"], scaling="strong", split=S.get("split_info"), host_ms=S["host_ms"])
 
     if rank == 0:
         info, ktimes = R["info"], R["ktimes"]
@@ -366,7 +468,7 @@ def main():
             "metric": "MPixels/sec JPEG->RGB (bit-exact BMP)", "value": main_rates["value"], "unit": "MPix/s",
             "value_mode": (f"{nfl} batches in flight (each resident batch on its own HIP stream; every step drained and checked before its batch is "
                            "decoded again); one_batch_in_flight = the same steps strictly serialised") if nfl > 1 else "one batch at a time",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, nfl),
+            "n_gpus": world, "rccl_ranks": comm["ranks"], "collective_backend": comm["backend"], "steps": args.steps, "warmup": max(args.warmup, nfl),
             "ms_per_step": main_rates["ms_per_step"], "higher_is_better": True, "scaling": "strong" if R.get("split") else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (integer IDCT), u8 out", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {R['label']}", "out_format": args.out_format,
@@ -400,6 +502,14 @@ def main():
                                                          "whole_step_frac": round(alg_bytes / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
         if variants:
             line["variants"] = variants
+        if R.get("split_info"):
+            line["split"] = R["split_info"]
+        if world > 1 and (args.workload == "cfg5split" or (args.workload == "cfg3" and not args.no_variants)):
+            # the C++ route to the same thing (pjd_split_decode: host threads + ONE ncclBroadcast), over the node's devices, in a child
+            rehearsal = "PJD_BENCH_DEVICE" in os.environ          # one-GPU rehearsal: every "rank" is that device (RCCL refuses duplicates: host copies)
+            if rehearsal:
+                os.environ["PJD_PIPE_ALLOW_DUP_DEVICES"] = "1"
+            line["cxx_split_decode"] = cxx_split_child(min(args.tile, 8192), 3, [local_rank] * world if rehearsal else range(world))
         if R.get("verify") is not None:
             line["verified_against_oracle"] = bool(R["verify"])
         jpegs = R["jpegs"]
@@ -416,6 +526,8 @@ def main():
                 "d2h_GBps": round(ps["out_bytes"] / ps["wall_s"] / 1e9, 2), "exact_kernel_images": ps["n_exact_images"],
                 "worker_ms": {k[:-2]: round(ps[k] * 1e3, 1) for k in ("scan_s", "create_s", "upload_s", "exec_s", "download_s")},
                 "note": "JPEG bytes in host memory -> BMP bytes in page-locked host memory; pictures are not consumed further"}
+        if world == 1 and not args.no_cli and args.workload in ("cfg3", "cfg3lite"):
+            line["cli_end_to_end"] = cli_end_to_end(jpegs, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(jpegs)
         print(json.dumps(line))
