@@ -23,18 +23,28 @@ static __constant__ uint8_t c_zz[64] = {
 //
 // All operands are within 24 bits when the inputs are int16 (they always are: dequantised coefficients and
 // first-pass outputs are stored as int16): |g| <= 32768*251/8, sums of two or three of those stay below 2^23.
-// __mul24 then returns exactly the low 32 bits of the reference's 32-bit product -- at full rate instead of the
+// v_mul_i32_i24 then returns exactly the low 32 bits of the reference's 32-bit product -- at full rate instead of the
 // quarter-rate v_mul_lo_u32.
+// sext24(a) * sext24(k), low 32 bits, in ONE full-rate instruction.  An instruction, not __mul24: for the second butterfly
+// stage (sums of first-stage terms) the compiler does not prove the 24-bit range and falls back to the quarter-rate 32-bit
+// multiply -- five per 1-D pass, a quarter of the pass's issue time (round 4, seen in the ISA).
+__device__ __forceinline__ int pjd_mul_i24(int a, int k)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a));
+    return r;
+}
+
 __device__ __forceinline__ void pjd_idct8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7, int *o)
 {
-    const int g0 = __mul24(x0, 181) >> 5, g1 = __mul24(x4, 181) >> 5;
-    const int g2 = __mul24(x2, 59) >> 3,  g3 = __mul24(x6, 49) >> 4;
-    const int g4 = __mul24(x5, 71) >> 4,  g5 = __mul24(x1, 251) >> 5;
-    const int g6 = __mul24(x7, 25) >> 4,  g7 = __mul24(x3, 213) >> 5;
+    const int g0 = pjd_mul_i24(x0, 181) >> 5, g1 = pjd_mul_i24(x4, 181) >> 5;
+    const int g2 = pjd_mul_i24(x2, 59) >> 3,  g3 = pjd_mul_i24(x6, 49) >> 4;
+    const int g4 = pjd_mul_i24(x5, 71) >> 4,  g5 = pjd_mul_i24(x1, 251) >> 5;
+    const int g6 = pjd_mul_i24(x7, 25) >> 4,  g7 = pjd_mul_i24(x3, 213) >> 5;
     const int f4 = g4 - g7, f5 = g5 + g6, f6 = g5 - g6, f7 = g4 + g7;
     const int e2 = g2 - g3, e3 = g2 + g3, e5 = f5 - f7, e7 = f5 + f7, e8 = f4 + f6;
-    const int d2 = __mul24(e2, 181) >> 7, d4 = __mul24(f4, 277) >> 8, d5 = __mul24(e5, 181) >> 7;
-    const int d6 = __mul24(f6, 669) >> 8, d8 = __mul24(e8, 49) >> 6;
+    const int d2 = pjd_mul_i24(e2, 181) >> 7, d4 = pjd_mul_i24(f4, 277) >> 8, d5 = pjd_mul_i24(e5, 181) >> 7;
+    const int d6 = pjd_mul_i24(f6, 669) >> 8, d8 = pjd_mul_i24(e8, 49) >> 6;
     const int c0 = g0 + g1, c1 = g0 - g1, c2 = d2 - e3, c4 = d4 + d8;
     const int c5 = d5 + e7, c6 = d6 - d8, c8 = c5 - c6;
     const int b0 = c0 + e3, b1 = c1 + c2, b2 = c1 - c2, b3 = c0 - e3, b4 = c4 - c8, b6 = c6 - e7;
@@ -57,6 +67,22 @@ __device__ __forceinline__ void pjd_ycc_to_rgb(int y, int cb, int cr, int &r, in
     r = pjd_clamp255(y + (__mul24(5880414, cr) >> 22) + 128);
     g = pjd_clamp255(y - (__mul24(1442840, cb) >> 22) - (__mul24(2994733, cr) >> 22) + 128);
     b = pjd_clamp255(y + (__mul24(7432306, cb) >> 22) + 128);
+}
+
+// Full-rate 24-bit multiplies as single instructions.  Written as instructions, not as __mul24 / __umul24: where only the low
+// 16 bits of a product are kept the compiler proves that the operand masks do not matter, drops them, and then has to use the
+// quarter-rate 32-bit multiply (v_mul_lo_u32) on the unmasked registers (seen in the entry parser of pjd_k_idct_colour_lanes).
+__device__ __forceinline__ uint32_t pjd_mul_u24(uint32_t a, uint32_t b)      // (a & 0xffffff) * (b & 0xffffff), low 32 bits
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pjd_mad_u24(uint32_t a, uint32_t b, uint32_t c)      // the same + c
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // Dequantise: short *= u32 with the product truncated to int16 on store

@@ -611,6 +611,13 @@ __device__ __forceinline__ uint32_t pjd_wave_prev(uint32_t v)
     return r;
 }
 
+// tile[u][pos] = v (low 16 bits), the row offset by one full-rate multiply-add
+__device__ __forceinline__ void pjd_tile_put(uint32_t tile_lds, uint32_t u, uint32_t pos, uint32_t v)
+{
+    const uint32_t a = pjd_mad_u24(u, TILE_STRIDE * 2u, tile_lds + 2u * pos);
+    *reinterpret_cast<__attribute__((address_space(3))) int16_t *>(a) = (int16_t)v;
+}
+
 __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdDevBatch B)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
@@ -685,6 +692,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     {
         // ltab: [0..31] groups before lane i of the window, [32..63] first_du - U0, [64..95] entries
         const uint32_t U0 = wg.first_mcu * dus;
+        const uint32_t tile_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int16_t *)&tile[0][0];
         const uint32_t g0 = mark.ent_off / PJD_GROUP;          // the range starts in this group of lane q
         // where the NEXT range starts (its mark) bounds this one; usable when every unit of this range was decoded
         uint32_t q_end = 0xffffffffu, g_end = 0;
@@ -746,7 +754,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                         if (on && (dc || f != 0) && pos < 64 && u < n_valid) {
                             const int val = dc ? (int)(int16_t)(sw & 0xffffu) : (int)(sw << 16) >> 21;
                             const uint32_t qe = dc ? 1u : qz[comp_of[u]][pos];             // (slot 52 under the quirk: position 64, quantiser 1)
-                            tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
+                            // the low 16 bits of value x quantiser (reference src/decoder_dpu.c:169-172) depend on the low 16 bits of both only
+                            pjd_tile_put(tile_lds, u, qe >> 16, pjd_mul_u24((uint32_t)val, qe));
                         }
                         if (on) {
                             const uint32_t ns = dc ? 1u : slot + f;
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                         if (onb && f != 0 && pos < 64 && u < n_valid) {
                             const int val = (int)sw >> 21;
                             const uint32_t qe = qz[comp_of[u]][pos];
-                            tile[u][qe >> 16] = (int16_t)pjd_dequant(val, qe & 0xffffu);
+                            pjd_tile_put(tile_lds, u, qe >> 16, pjd_mul_u24((uint32_t)val, qe));
                         }
                         if (onb) {
                             const uint32_t ns = slot + f;

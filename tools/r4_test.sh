@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu ${TESTS:+-k "$TESTS"} > gpurun_out/r4_test.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -15 gpurun_out/r4_test.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 400 python bench.py --e2e-batches 0 --no-cpu-baseline > gpurun_out/r4_bench.log 2> gpurun_out/r4_bench.err; echo "bench rc=$?"
+timeout -k 10 400 python bench.py --e2e-batches 0 --no-cpu-baseline --no-cli > gpurun_out/r4_bench.log 2> gpurun_out/r4_bench.err; echo "bench rc=$?"
 python3 - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r4_bench.log').read().strip().splitlines()[-1])
