@@ -279,7 +279,19 @@ struct ChkCtx {            // checkpoint bookkeeping of one lane (LDS, strided b
     uint32_t walk_max;     // wave-uniform: rounds with at most this many active lanes are walked (walk_lane)
 };
 
-enum { SPAN_END = 0, SPAN_MERGED = 1 };
+enum { SPAN_END = 0, SPAN_MERGED = 1, SPAN_MERGED_B = 2 };
+
+// One more landing pad per lane, in registers ("B"): the state an OLDER trajectory of the lane had at the first checkpoint, the units
+// that follow it, and that trajectory's exit state.  Truth moves through a run of non-merging lanes one lane per round, and every hop
+// is a full pass of a lane whose new entry leads to a trajectory it has not decoded before; the entry states a lane sees differ mostly
+// in the MCU phase, there are only a few of those, and a pass from a phase seen the round before last used to be decoded again in
+// full because only the newest trajectory's checkpoints are kept (LDS).  With B such a pass ends at the first checkpoint (90 % of all
+// merges happen there).  Model (tools/sync_sim.c, sim_rounds_b): -12 % round time per wave, -16 % on the slowest wave of dense pictures.
+struct BCache {
+    uint32_t st;           // packed state at checkpoint 1 (as sync_span's `st`); 0xffffffff: empty
+    uint32_t rem;          // data units from there to the end of the subsequence
+    uint32_t p, cz;        // exit state of that trajectory (as WaveState)
+};
 
 // After a sync pass: checkpoints (re)written in it hold "units so far"; make them "units still to come".
 __device__ __forceinline__ void chk_finish(const ChkCtx &K, uint32_t j, uint32_t ndu)
@@ -315,13 +327,17 @@ __device__ __forceinline__ uint32_t add_flag(uint32_t v, bool f)
 // come); otherwise (re)write the checkpoints passed.  Returns the number of checkpoints passed + 1 in `jout`.
 // Inside the loop the slot is kept as zb = 63 - z (63: DC expected) and the phase as the LDS address of the unit's
 // phase record: one symbol is a table lookup, "zb -= advance", and three selects when the unit is complete.
+// BRIDGE also compares the state at checkpoint 1 with Bst (the lane's BCache) and returns SPAN_MERGED_B on a match (ndu then does
+// NOT include B's units yet); oldA_st / oldA_rem: what the newest trajectory held at checkpoint 1 if this pass crossed it without
+// merging into it (0xffffffff otherwise): the caller's next B.
 template <bool BRIDGE>
 __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words, uint32_t col,
                                          uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
-                                         uint32_t &ndu, const ChkCtx &K, uint32_t &jout)
+                                         uint32_t &ndu, const ChkCtx &K, uint32_t &jout, uint32_t Bst, uint32_t &oldA_st, uint32_t &oldA_rem)
 {
     uint32_t j = 1;
     jout = 1;
+    oldA_st = 0xffffffffu; oldA_rem = 0;
     if (p >= end_bit) return SPAN_END;
     BitWin w;
     w.init(wave_words, col, p);
@@ -359,7 +375,14 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
         if (p >= lim) {
             if (p >= end_bit) break;
             const uint32_t st = (p << 14) | ((ra - P.xbase) << 6) | (uint32_t)zb;      // p < 2^14, record offset < 256, zb < 64
-            if (BRIDGE && K.state[j * 64] == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
+            if (BRIDGE) {
+                const uint32_t a = K.state[j * 64];
+                if (a == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
+                if (j == 1) {
+                    oldA_st = a; oldA_rem = K.rem[64];
+                    if (st == Bst) { res = SPAN_MERGED_B; break; }
+                }
+            }
             K.state[j * 64] = st;
             K.rem[j * 64] = ndu;                                            // turned into "still to come" after the pass
             j++;
@@ -422,12 +445,15 @@ struct WalkBuf {
 };
 
 // All arguments but `l` are wave-uniform.  st_col / rem_col: the checkpoint columns of the lane that is walked.
+// Bst / oldA_st / oldA_rem: as sync_span (the walked lane's BCache state; all wave-uniform).
 __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_t l, uint32_t base_bit,
                                          uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit, uint32_t &ndu,
-                                         uint32_t *st_col, uint32_t *rem_col, uint32_t chk_bits, uint32_t &jout)
+                                         uint32_t *st_col, uint32_t *rem_col, uint32_t chk_bits, uint32_t &jout,
+                                         uint32_t Bst, uint32_t &oldA_st, uint32_t &oldA_rem)
 {
     uint32_t j = 1;
     jout = 1;
+    oldA_st = 0xffffffffu; oldA_rem = 0;
     if (p >= end_bit) return SPAN_END;
     // scalar copies (intrinsic results, not loads from the context struct: selects between them stay selects)
     const uint32_t tY = rfl(P.tY), tC1 = rfl(P.tC1), tC2 = rfl(P.tC2), nc = rfl(P.nc), dus1 = rfl(P.dus1), lbase = rfl(P.lbase);
@@ -503,7 +529,12 @@ __device__ __forceinline__ int walk_lane(const PhaseCtx &P, WalkBuf &wb, uint32_
         if (p >= lim) {
             if (p >= end_bit) break;
             const uint32_t st = (p << 14) | (r << 10) | (uint32_t)zb;                        // as sync_span: record offset r * 16 << 6
-            if (rfl(st_col[j * 64]) == st) { ndu += rfl(rem_col[j * 64]); res = SPAN_MERGED; break; }
+            const uint32_t a = rfl(st_col[j * 64]);
+            if (a == st) { ndu += rfl(rem_col[j * 64]); res = SPAN_MERGED; break; }
+            if (j == 1) {
+                oldA_st = a; oldA_rem = rfl(rem_col[64]);
+                if (st == Bst) { res = SPAN_MERGED_B; break; }
+            }
             if (l == 0) { st_col[j * 64] = st; rem_col[j * 64] = ndu; }
             j++;
             next_chk += chk_bits;
@@ -776,7 +807,7 @@ struct WaveState { uint32_t p_img, cz, cnt; };
 
 // Re-sync rounds inside one wave.  `changed`: this lane's exit state is new to its successor.  Lane 0 takes its
 // predecessor's exit from (ext_p, ext_cz) in the first round if `ext_new`.
-__device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g, const ChkCtx &K, WalkBuf &wb, WaveState &S, uint32_t changed,
+__device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g, const ChkCtx &K, WalkBuf &wb, WaveState &S, BCache &Bc, uint32_t changed,
                                             uint32_t ext_p, uint32_t ext_cz, bool ext_new, uint32_t &err_acc,
                                             unsigned long long *stats, int stat_base, uint32_t *rdbg)
 {
@@ -811,12 +842,24 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
                     const uint32_t endb = (uint32_t)__builtin_amdgcn_readlane((int)g.end_bit, (int)a);
                     uint32_t p = ep - base, c = ecz >> 8, z = ecz & 255u, ndu = 0, j;
                     uint32_t *st_col = K.state - l + a, *rem_col = K.rem - l + a;
-                    const int res = walk_lane(P, wb, l, base, p, c, z, endb, ndu, st_col, rem_col, chk_bits, j);
-                    if (l == 0) for (uint32_t i = 1; i < j; i++) rem_col[i * 64] = ndu - rem_col[i * 64];      // chk_finish
+                    const uint32_t Bst_a = (uint32_t)__builtin_amdgcn_readlane((int)Bc.st, (int)a);
+                    uint32_t oa_st, oa_rem;
+                    const int res = walk_lane(P, wb, l, base, p, c, z, endb, ndu, st_col, rem_col, chk_bits, j, Bst_a, oa_st, oa_rem);
                     walked++;
-                    const uint32_t np = p + base, ncz = (c << 8) | z;
                     const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)S.p_img, (int)a), ocz = (uint32_t)__builtin_amdgcn_readlane((int)S.cz, (int)a);
-                    if (l == a) S.cnt = ndu;
+                    uint32_t np = p + base, ncz = (c << 8) | z;
+                    if (res == SPAN_MERGED_B) {
+                        // the walk met the lane's cached older trajectory at checkpoint 1: that one is the lane's trajectory now, and the
+                        // one it replaces becomes the cache
+                        const uint32_t Brem_a = (uint32_t)__builtin_amdgcn_readlane((int)Bc.rem, (int)a);
+                        np = (uint32_t)__builtin_amdgcn_readlane((int)Bc.p, (int)a); ncz = (uint32_t)__builtin_amdgcn_readlane((int)Bc.cz, (int)a);
+                        ndu += Brem_a;
+                        if (l == 0) { st_col[64] = Bst_a; rem_col[64] = Brem_a; st_col[128] = 0xffffffffu; st_col[192] = 0xffffffffu; }
+                    } else if (l == 0) for (uint32_t i = 1; i < j; i++) rem_col[i * 64] = ndu - rem_col[i * 64];      // chk_finish
+                    if (l == a) {
+                        S.cnt = ndu;
+                        if (oa_st != 0xffffffffu || res == SPAN_MERGED_B) { Bc.st = oa_st; Bc.rem = oa_rem; Bc.p = op; Bc.cz = ocz; }
+                    }
                     if (res == SPAN_MERGED || (np == op && ncz == ocz)) break;
                     if (l == a) { S.p_img = np; S.cz = ncz; }
                     // the successor has a new entry state: go on into it
@@ -833,14 +876,24 @@ __device__ __forceinline__ bool wave_rounds(const PhaseCtx &P, const LaneGeom &g
         if (stats && l == 0) { atomicAdd(stats + stat_base, 1ull); atomicAdd(stats + stat_base + 1, (unsigned long long)__popcll(act_mask)); }
         changed = 0;
         if (act) {
-            uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, j;
-            const int res = sync_span<true>(P, g.words, g.col, p, c, z, g.end_bit, ndu, K, j);
-            chk_finish(K, j, ndu);               // also after a merge: ndu then includes the units still to come
-            S.cnt = ndu;
-            if (res != SPAN_MERGED) {
-                const uint32_t np = p + g.base_bit, ncz = (c << 8) | z;
-                if (np != S.p_img || ncz != S.cz) { S.p_img = np; S.cz = ncz; changed = 1; }
+            uint32_t p = pp - g.base_bit, c = pcz >> 8, z = pcz & 255, ndu = 0, j, oa_st, oa_rem;
+            const int res = sync_span<true>(P, g.words, g.col, p, c, z, g.end_bit, ndu, K, j, Bc.st, oa_st, oa_rem);
+            const uint32_t op = S.p_img, ocz = S.cz;
+            if (res == SPAN_MERGED_B) {
+                // met the cached older trajectory at checkpoint 1: it is the lane's trajectory now (its later checkpoints are not known)
+                ndu += Bc.rem;
+                K.state[64] = Bc.st; K.rem[64] = Bc.rem; K.state[128] = 0xffffffffu; K.state[192] = 0xffffffffu;
+                if (Bc.p != S.p_img || Bc.cz != S.cz) { S.p_img = Bc.p; S.cz = Bc.cz; changed = 1; }
+            } else {
+                chk_finish(K, j, ndu);           // also after a merge: ndu then includes the units still to come
+                if (res != SPAN_MERGED) {
+                    const uint32_t np = p + g.base_bit, ncz = (c << 8) | z;
+                    if (np != S.p_img || ncz != S.cz) { S.p_img = np; S.cz = ncz; changed = 1; }
+                }
             }
+            S.cnt = ndu;
+            // the trajectory this pass left at checkpoint 1 (with the exit it had) is the cache now
+            if (oa_st != 0xffffffffu || res == SPAN_MERGED_B) { Bc.st = oa_st; Bc.rem = oa_rem; Bc.p = op; Bc.cz = ocz; }
         }
         if (rdbg && l == 0 && iter < 24) rdbg[iter] = ((uint32_t)__popcll(act_mask) << 24) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - tr0) & 0xffffffu);
     }
@@ -1028,7 +1081,8 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     {
         uint32_t p = 0, c = 0, z = 0, ndu = 0, j = 1;
         if (g.valid) {
-            sync_span<false>(P, g.words, g.col, p, c, z, g.end_bit, ndu, K, j);
+            uint32_t oa, orem;
+            sync_span<false>(P, g.words, g.col, p, c, z, g.end_bit, ndu, K, j, 0xffffffffu, oa, orem);
             chk_finish(K, j, ndu);
         }
         S.p_img = p + g.base_bit; S.cz = (c << 8) | z; S.cnt = ndu;
@@ -1045,7 +1099,9 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     wb.clamp = rfl(im.ecs_len) + 40u;                      // >= 48 zero bytes follow every stream (pjd_plan.cpp)
     wb.cb = 0; wb.cw = 0; wb.cn = 0; wb.have = 0;
     if (!first_is_head) entry_used = op_wait_flag(genA + w - 1, dead);
-    ok = wave_rounds(P, g, K, wb, S, g.valid ? 1u : 0u, (uint32_t)entry_used,
+    BCache Bc;
+    Bc.st = 0xffffffffu; Bc.rem = 0; Bc.p = 0; Bc.cz = 0;
+    ok = wave_rounds(P, g, K, wb, S, Bc, g.valid ? 1u : 0u, (uint32_t)entry_used,
                      (((uint32_t)(entry_used >> 32) & 255) << 8) | ((uint32_t)(entry_used >> 40) & 255), !first_is_head && !dead,
                      err_acc, B.stats, 0, B.dbg ? B.dbg + (size_t)w * 32 + 8 : nullptr);
     if (l == last_lane) op_store(genB + w, pjd_pack_state(S.p_img, S.cz >> 8, S.cz & 255) | OP_FLAG);
@@ -1059,7 +1115,7 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
             const uint64_t truth = op_wait_flag(B.wave_gen + (size_t)gen * B.n_hwave + w - 1, dead);
             if (!dead && truth != entry_used) {
                 entry_used = truth;
-                ok = wave_rounds(P, g, K, wb, S, 0u, (uint32_t)truth,
+                ok = wave_rounds(P, g, K, wb, S, Bc, 0u, (uint32_t)truth,
                                  (((uint32_t)(truth >> 32) & 255) << 8) | ((uint32_t)(truth >> 40) & 255), true,
                                  err_acc, B.stats, 2, nullptr) && ok;
             }

@@ -389,3 +389,160 @@ long sim_hyp_sets(const Sim *s, int S, const int *masks, int nmasks, long *out)
     }
     return n;
 }
+
+// The GPU's rounds with ONE extra cached state per lane ("B"): the state an older trajectory had at the FIRST checkpoint, with the units
+// that follow it and that trajectory's exit state.  A pass that crosses checkpoint 1 in state B ends there (exit = B's exit) and the
+// roles swap; a pass that crosses it merging with neither moves the newest trajectory's first checkpoint (and exit) into B.
+// spec2 >= 0: the speculative pass is followed by a second one from start phase `spec2`, which fills B.
+// out[] as sim_rounds_keep (+ out[7] = bytes decoded in the second speculative pass)
+typedef struct { St st; St exit; int valid; } BCache;
+void sim_rounds_b(const Sim *s, int S, int nchk, int spec2, int use_b, long *out)
+{
+    const long nbytes = s->nbits / 8;
+    const int nl = (int)((nbytes + S - 1) / S);
+    St *ex = calloc(nl, sizeof(St));
+    Traj *A = calloc(nl, sizeof(Traj));
+    BCache *Bc = calloc(nl, sizeof(BCache));
+    uint8_t *chg = calloc(nl + 1, 1), *nchg = calloc(nl + 1, 1);
+    memset(out, 0, 40 * sizeof(long));
+    int dummy = 0; long len;
+    for (int k = 0; k < nl; k++) {
+        St in = { (long)k * S * 8, 0, 0 };
+        ex[k] = run_lane_merge(s, in, (long)k * S * 8, (long)(k + 1) * S * 8, nchk, A + k, 0, 1, &len, &dummy, A + k);
+        chg[k] = 1;
+        if (spec2 >= 0 && use_b) {
+            Traj t2; St in2 = { (long)k * S * 8, 0, spec2 % s->dus };
+            // stops early if it meets the first trajectory at a checkpoint
+            St e2 = run_lane_merge(s, in2, (long)k * S * 8, (long)(k + 1) * S * 8, nchk, A + k, 1, 1, &len, &dummy, &t2);
+            out[7] += len / 8;
+            if (t2.nchk >= 1 && !(t2.chk[0].p == A[k].chk[0].p && t2.chk[0].z == A[k].chk[0].z && t2.chk[0].c == A[k].chk[0].c)) { Bc[k].st = t2.chk[0]; Bc[k].exit = e2; Bc[k].valid = 1; }
+        }
+    }
+    const int nw = (nl + 63) / 64;
+    long *wt = calloc(nw, sizeof(long)), *wr = calloc(nw, sizeof(long));
+    for (int round = 1; round < 4096; round++) {
+        int any = 0;
+        memset(nchg, 0, nl + 1);
+        St *nex = malloc(nl * sizeof(St));
+        memcpy(nex, ex, nl * sizeof(St));
+        long *wmax = calloc(nw, sizeof(long));
+        for (int k = 1; k < nl; k++) {
+            if (!chg[k - 1]) continue;
+            // decode from the predecessor's exit; at checkpoint 1 also compare with B
+            St in = ex[k - 1];
+            const long start_bit = (long)k * S * 8, end_bit = (long)(k + 1) * S * 8, span = (end_bit - start_bit) / nchk;
+            long ndu = 0, next = start_bit + span; int j = 1;
+            const long p0 = in.p;
+            Traj rec; rec.nchk = 0;
+            St e; int done = 0;
+            const St oldA1 = A[k].chk[0]; const int oldA_has1 = A[k].nchk >= 1; const St old_exit = ex[k];
+            while (in.p < end_bit && in.p < s->nbits && !done) {
+                if (step(s, &in.p, &in.z, &in.c, &ndu, 1)) break;
+                if (in.p >= next && j < nchk && in.p < end_bit) {
+                    if (A[k].nchk >= j && A[k].chk[j - 1].p == in.p && A[k].chk[j - 1].z == in.z && A[k].chk[j - 1].c == in.c) {
+                        for (int q = j - 1; q < A[k].nchk; q++) rec.chk[q] = A[k].chk[q];
+                        rec.nchk = A[k].nchk; e = A[k].exit; done = 1; break;
+                    }
+                    if (use_b && j == 1 && Bc[k].valid && Bc[k].st.p == in.p && Bc[k].st.z == in.z && Bc[k].st.c == in.c) {
+                        rec.chk[0] = in; rec.nchk = 1; e = Bc[k].exit; done = 2; out[6]++; break;
+                    }
+                    rec.chk[j - 1] = in; rec.nchk = j;
+                    j++; next += span;
+                }
+            }
+            if (!done) e = in;
+            len = in.p - p0;
+            rec.exit = e;
+            // B takes over the newest trajectory's first checkpoint when the pass crossed checkpoint 1 without merging into A there
+            if (use_b && oldA_has1 && rec.nchk >= 1 && !(rec.chk[0].p == oldA1.p && rec.chk[0].z == oldA1.z && rec.chk[0].c == oldA1.c)) { Bc[k].st = oldA1; Bc[k].exit = old_exit; Bc[k].valid = 1; }
+            A[k] = rec;
+            out[3] += len / 8;
+            if (len / 8 > wmax[k / 64]) wmax[k / 64] = len / 8;
+            if (e.p != ex[k].p || e.z != ex[k].z || e.c != ex[k].c) { nex[k] = e; nchg[k] = 1; any = 1; }
+        }
+        for (int w = 0; w < nw; w++) if (wmax[w]) { wt[w] += wmax[w]; wr[w]++; }
+        free(wmax);
+        memcpy(ex, nex, nl * sizeof(St)); free(nex);
+        memcpy(chg, nchg, nl + 1);
+        if (!any) break;
+    }
+    for (int w = 0; w < nw; w++) { out[0] += wt[w]; if (wt[w] > out[1]) out[1] = wt[w]; out[4] += wr[w]; if (wr[w] > out[5]) out[5] = wr[w]; }
+    out[2] = nw;
+    free(ex); free(A); free(Bc); free(chg); free(nchg); free(wt); free(wr);
+}
+
+// QUANTUM rounds: a round lasts one checkpoint interval.  Every lane is a small machine: IDLE, or RUNNING a decode from some entry
+// state towards its subsequence end, one checkpoint interval per quantum.  At a checkpoint crossing the state is compared with the
+// newest trajectory's (A) and, at checkpoint 1, with the cached B: a match ends the run (the exit is known).  A run that ends with a
+// NEW exit restarts its successor from it in the next quantum (a successor still running from an older entry is restarted).
+// out[0] = sum over waves of quanta, out[1] = quanta of the slowest wave, out[2] = waves, out[3] = lane-quanta executed (work),
+// out[4] = bytes decoded
+typedef struct { int running; St cur; long ndu; int j; Traj rec; St entry; } Mach;
+void sim_quanta(const Sim *s, int S, int nchk, int use_b, long *out)
+{
+    const long nbytes = s->nbits / 8;
+    const int nl = (int)((nbytes + S - 1) / S);
+    St *ex = calloc(nl, sizeof(St));
+    Traj *A = calloc(nl, sizeof(Traj));
+    BCache *Bc = calloc(nl, sizeof(BCache));
+    Mach *M = calloc(nl, sizeof(Mach));
+    memset(out, 0, 40 * sizeof(long));
+    int dummy = 0; long len;
+    for (int k = 0; k < nl; k++) {
+        St in = { (long)k * S * 8, 0, 0 };
+        ex[k] = run_lane_merge(s, in, (long)k * S * 8, (long)(k + 1) * S * 8, nchk, A + k, 0, 1, &len, &dummy, A + k);
+    }
+    // after the speculative pass every lane but the first of the picture is started from its predecessor's exit
+    for (int k = 1; k < nl; k++) { M[k].running = 1; M[k].cur = ex[k - 1]; M[k].entry = ex[k - 1]; M[k].ndu = 0; M[k].j = 1; M[k].rec.nchk = 0; }
+    const int nw = (nl + 63) / 64;
+    long *wq = calloc(nw, sizeof(long));
+    for (int q = 1; q < 100000; q++) {
+        int any = 0;
+        uint8_t *wa = calloc(nw, 1);
+        St *newexit = malloc(nl * sizeof(St)); uint8_t *has = calloc(nl, 1);
+        for (int k = 1; k < nl; k++) {
+            if (!M[k].running) continue;
+            any = 1; wa[k / 64] = 1; out[3]++;
+            Mach *m = &M[k];
+            const long start_bit = (long)k * S * 8, end_bit = (long)(k + 1) * S * 8, span = (end_bit - start_bit) / nchk;
+            const long next = start_bit + span * m->j;
+            const long p0 = m->cur.p;
+            int fin = 0; St e;
+            // decode until the next checkpoint boundary (or the end)
+            while (m->cur.p < end_bit && m->cur.p < s->nbits) {
+                if (step(s, &m->cur.p, &m->cur.z, &m->cur.c, &m->ndu, 1)) break;
+                if (m->cur.p >= next && m->j < nchk) break;
+            }
+            out[4] += (m->cur.p - p0) / 8;
+            if (m->cur.p >= end_bit || m->cur.p >= s->nbits || m->j >= nchk) {
+                if (m->cur.p >= end_bit || m->cur.p >= s->nbits) { fin = 1; e = m->cur; }
+            }
+            if (!fin) {
+                const int j = m->j;
+                if (A[k].nchk >= j && A[k].chk[j - 1].p == m->cur.p && A[k].chk[j - 1].z == m->cur.z && A[k].chk[j - 1].c == m->cur.c) {
+                    for (int t = j - 1; t < A[k].nchk; t++) m->rec.chk[t] = A[k].chk[t];
+                    m->rec.nchk = A[k].nchk; e = A[k].exit; fin = 1;
+                } else if (use_b && j == 1 && Bc[k].valid && Bc[k].st.p == m->cur.p && Bc[k].st.z == m->cur.z && Bc[k].st.c == m->cur.c) {
+                    m->rec.chk[0] = m->cur; m->rec.nchk = 1; e = Bc[k].exit; fin = 1;
+                } else { m->rec.chk[j - 1] = m->cur; m->rec.nchk = j; m->j++; }
+            }
+            if (fin) {
+                m->running = 0;
+                m->rec.exit = e;
+                if (use_b && A[k].nchk >= 1 && m->rec.nchk >= 1 && !(m->rec.chk[0].p == A[k].chk[0].p && m->rec.chk[0].z == A[k].chk[0].z && m->rec.chk[0].c == A[k].chk[0].c)) { Bc[k].st = A[k].chk[0]; Bc[k].exit = ex[k]; Bc[k].valid = 1; }
+                A[k] = m->rec;
+                if (e.p != ex[k].p || e.z != ex[k].z || e.c != ex[k].c) { newexit[k] = e; has[k] = 1; }
+            }
+        }
+        for (int k = 1; k < nl; k++) if (has[k]) {
+            ex[k] = newexit[k];
+            if (k + 1 < nl) { Mach *m = &M[k + 1]; m->running = 1; m->cur = ex[k]; m->entry = ex[k]; m->ndu = 0; m->j = 1; m->rec.nchk = 0; }
+        }
+        for (int w = 0; w < nw; w++) wq[w] += wa[w];
+        free(wa); free(newexit); free(has);
+        if (!any) break;
+    }
+    for (int w = 0; w < nw; w++) { out[0] += wq[w]; if (wq[w] > out[1]) out[1] = wq[w]; }
+    out[2] = nw;
+    free(ex); free(A); free(Bc); free(M); free(wq);
+}
