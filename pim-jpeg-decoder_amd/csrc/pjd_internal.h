@@ -278,6 +278,17 @@ struct PjdDevIdctWg {                  // one IDCT/colour workgroup = one coeffi
     uint32_t pad_;
 };
 
+// One picture GROUP: pictures of similar stream density, decoded by its own chain of launches (entropy decode -> DC predictors ->
+// back end) beside the other groups' chains, so that the back end of the light pictures runs while the dense pictures' chains of
+// re-sync rounds are still finishing (round 4: one batch alone was entropy-decode tail + the whole back end, one after the other).
+#define PJD_MAX_GROUPS 8
+struct PjdDevGroup {
+    uint32_t hwg_first, hwg_count;     // its Huffman workgroups: a range of PjdDevBatch::hwgs (start order: densest pictures first)
+    uint32_t img_first, img_count;     // its pictures: a range of PjdDevBatch::group_images
+    uint32_t iwg_first, iwg_count;     // its back-end workgroups: a range of PjdDevBatch::iwg_order
+    uint32_t pad_[2];
+};
+
 // what a Huffman lane leaves behind for the back end (written at the end of its write pass)
 struct PjdDevLaneInfo {
     uint32_t n_ent;                    // slots used in the lane's region (group heads included; two per step word)

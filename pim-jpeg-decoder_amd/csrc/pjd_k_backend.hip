@@ -618,7 +618,8 @@ __device__ __forceinline__ void pjd_tile_put(uint32_t tile_lds, uint32_t u, uint
     *reinterpret_cast<__attribute__((address_space(3))) int16_t *>(a) = (int16_t)v;
 }
 
-__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdDevBatch B)
+// order: the launch's workgroup -> index into PjdDevBatch::iwgs / marks (null: the identity, one launch for the whole batch)
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdDevBatch B, const uint32_t *__restrict__ order)
 {
     __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
     __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
@@ -630,7 +631,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 #if PJD_IDCT_PRIO
     __builtin_amdgcn_s_setprio(PJD_IDCT_PRIO);
 #endif
-    const PjdDevIdctWg wg = B.iwgs[blockIdx.x];
+    const uint32_t iwg = order ? order[blockIdx.x] : blockIdx.x;
+    const PjdDevIdctWg wg = B.iwgs[iwg];
     const PjdDevImage &im = B.images[wg.image];
     if ((im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT)) return;   // the dense path redoes it
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     const unsigned long long err_key = B.imstate[wg.image].err_key;
     const uint32_t n_valid = pjd_units_decoded(err_key, wg.first_mcu * dus, n_du);
     const uint32_t err_byte = (uint32_t)(err_key >> 35);       // byte of the stream the offending symbol starts in (bit positions fit 32 bits); no error: past every lane
-    const PjdDevMark mark = B.marks[blockIdx.x];
+    const PjdDevMark mark = B.marks[iwg];
     const uint32_t lane_end = im.lane_base + im.n_lane;
     uint32_t q = mark.lane, n = mark.ent_off;
     (void)n;
@@ -696,8 +698,8 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         const uint32_t g0 = mark.ent_off / PJD_GROUP;          // the range starts in this group of lane q
         // where the NEXT range starts (its mark) bounds this one; usable when every unit of this range was decoded
         uint32_t q_end = 0xffffffffu, g_end = 0;
-        if (n_valid == n_du && blockIdx.x + 1 < im.iwg_base + im.n_iwg) {
-            const PjdDevMark nm = B.marks[blockIdx.x + 1];
+        if (n_valid == n_du && iwg + 1 < im.iwg_base + im.n_iwg) {
+            const PjdDevMark nm = B.marks[iwg + 1];
             if (nm.lane >= q && nm.lane < lane_end) { q_end = nm.lane; g_end = nm.ent_off / PJD_GROUP; }
         }
         for (uint32_t qw = q; n_valid != 0; qw += 32) {
@@ -851,7 +853,83 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
 void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b)
 {
     if (b.n_iwg == 0) return;
-    hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(b.n_iwg), dim3(PJD_IDCT_THREADS), 0, s, b);
+    hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(b.n_iwg), dim3(PJD_IDCT_THREADS), 0, s, b, (const uint32_t *)nullptr);
+}
+
+void pjd_launch_group_idct(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g)
+{
+    if (g.iwg_count) hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(g.iwg_count), dim3(PJD_IDCT_THREADS), 0, s, b, b.iwg_order + g.iwg_first);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One picture group: verdict and DC predictors per PICTURE, one workgroup each (pictures of a group are small: the planner makes
+// groups only if no picture has more than 8192 lanes).  The same results as pjd_k_image_verdict + pjd_k_lane_dc_local / _carry leave,
+// with every lane's predictors absolute (PjdDevLaneDc::abs = 1: no block carry to add).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PJD_DC_BLOCK) void pjd_k_group_dc(PjdDevBatch B, const uint32_t *__restrict__ images)
+{
+    __shared__ uint32_t sy[PJD_DC_BLOCK], scb[PJD_DC_BLOCK], scr[PJD_DC_BLOCK], sf[PJD_DC_BLOCK];
+    const uint32_t i = images[blockIdx.x], tid = threadIdx.x;
+    const PjdDevImage &im = B.images[i];
+    if (tid == 0) {                                            // pjd_k_image_verdict
+        const int32_t st = B.status[i];
+        if (!(st & PJD_STW_NEEDS_EXACT)) {
+            const PjdDevImState s = B.imstate[i];
+            const bool has_err = s.err_key != ~0ull;
+            const uint32_t err_pos = (uint32_t)(s.err_key >> 32);
+            if (s.flag_pos != 0xffffffffu && (!has_err || s.flag_pos <= err_pos)) B.status[i] = st | PJD_STW_NEEDS_EXACT;
+            else if (has_err) B.status[i] = (int32_t)((s.err_key >> 1) & 7u);
+        }
+    }
+    uint32_t cy = 0, ccb = 0, ccr = 0;                         // predictors entering the current chunk of lanes
+    for (uint32_t base = 0; base < im.n_lane; base += PJD_DC_BLOCK) {
+        const uint32_t q = im.lane_base + base + tid;
+        const bool on = base + tid < im.n_lane;
+        uint32_t vy = 0, vcb = 0, vcr = 0, head = 0;
+        if (on) {
+            const PjdDevLaneInfo li = B.lane_info[q];
+            vy = li.dc_sum[0]; vcb = li.dc_sum[1]; vcr = li.dc_sum[2]; head = li.first_du >> 31;
+        }
+        sy[tid] = vy; scb[tid] = vcb; scr[tid] = vcr; sf[tid] = head;
+        __syncthreads();
+        for (uint32_t off = 1; off < PJD_DC_BLOCK; off <<= 1) {      // Hillis-Steele inclusive segmented scan
+            uint32_t ay = 0, acb = 0, acr = 0, af = 0;
+            const bool take = tid >= off;
+            if (take) { ay = sy[tid - off]; acb = scb[tid - off]; acr = scr[tid - off]; af = sf[tid - off]; }
+            const uint32_t myf = sf[tid];
+            __syncthreads();
+            if (take) {
+                if (!myf) { sy[tid] += ay; scb[tid] += acb; scr[tid] += acr; }
+                sf[tid] = myf | af;
+            }
+            __syncthreads();
+        }
+        if (on) {
+            // predictors entering this lane: zero at a segment head; else what the lanes before it leave -- inside the chunk, plus the
+            // chunk's carry-in unless a head lies between the chunk start and this lane
+            PjdDevLaneDc d;
+            d.dc_in[0] = d.dc_in[1] = d.dc_in[2] = 0;
+            d.abs = 1;
+            if (!head) {
+                uint32_t py = cy, pcb = ccb, pcr = ccr;
+                if (tid > 0) {
+                    const bool h = sf[tid - 1] != 0;
+                    py = (h ? 0u : cy) + sy[tid - 1]; pcb = (h ? 0u : ccb) + scb[tid - 1]; pcr = (h ? 0u : ccr) + scr[tid - 1];
+                }
+                d.dc_in[0] = (uint16_t)py; d.dc_in[1] = (uint16_t)pcb; d.dc_in[2] = (uint16_t)pcr;
+            }
+            B.lane_dc[q] = d;
+        }
+        const bool h = sf[PJD_DC_BLOCK - 1] != 0;
+        const uint32_t ny = (h ? 0u : cy) + sy[PJD_DC_BLOCK - 1], ncb = (h ? 0u : ccb) + scb[PJD_DC_BLOCK - 1], ncr = (h ? 0u : ccr) + scr[PJD_DC_BLOCK - 1];
+        __syncthreads();
+        cy = ny; ccb = ncb; ccr = ncr;
+    }
+}
+
+void pjd_launch_group_dc(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g)
+{
+    if (g.img_count) hipLaunchKernelGGL(pjd_k_group_dc, dim3(g.img_count), dim3(PJD_DC_BLOCK), 0, s, b, b.group_images + g.img_first);
 }
 
 void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b)

@@ -982,14 +982,16 @@ __device__ __forceinline__ uint64_t op_wait_flag(const uint64_t *p, bool &timeou
 //   * data-unit counts (segmented: a restart segment's first subsequence resets to the segment's first
 //     unit) are combined with a decoupled look-back over the image's waves, 64 descriptors per step;
 //   * the write pass runs from registers; tables are still in LDS, the checkpoint area becomes the staging buffer.
-__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch B)
+// hwg_base / ticket: the launch covers workgroups hwg_base .. of PjdDevBatch::hwgs and draws their indices from its own ticket
+// counter (one launch for the whole batch: 0 and B.ticket; one per picture group otherwise, pjd_internal.h).
+__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch B, uint32_t hwg_base, uint32_t *__restrict__ ticket)
 {
     const uint32_t t = threadIdx.x, l = t & 63, wi = t >> 6;
     uint8_t *lds = pjd_huff_lds;
     uint8_t *areas = lds + B.max_lut_bytes;
     uint8_t *phase_tabs = areas + PJD_HUFF_WAVES * PJD_WAVE_LDS;
     uint32_t *tick = reinterpret_cast<uint32_t *>(phase_tabs + PJD_HUFF_WAVES * PJD_PHASE_LDS);
-    if (t == 0) *tick = atomicAdd(B.ticket, 1u);
+    if (t == 0) *tick = hwg_base + atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t gidx = rfl(*tick);
     const PjdDevHuffWg wg = B.hwgs[gidx];
@@ -1435,5 +1437,10 @@ void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b)
 }
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b)
 {
-    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_lanes, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b);
+    if (b.n_hwg) hipLaunchKernelGGL(pjd_k_huff_lanes, dim3(b.n_hwg), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b, 0u, b.ticket);
+}
+void pjd_launch_huff_lanes_group(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g, uint32_t group_index)
+{
+    // ticket counters: the batch's, then one per group (the operation state is zeroed before every decode, pjd_k_reset)
+    if (g.hwg_count) hipLaunchKernelGGL(pjd_k_huff_lanes, dim3(g.hwg_count), dim3(PJD_HUFF_THREADS), huff_lds_bytes(b), s, b, g.hwg_first, b.ticket + 2 + 2 * group_index);
 }

@@ -18,6 +18,8 @@ struct PjdDevBatch {
     const PjdDevHuffWg *hwgs;
     const PjdDevIdctWg *iwgs;
     const PjdDevScan *pscans;            // scans of the progressive frames of the batch (PjdDevImage::pscan_base)
+    const uint32_t *group_images;        // picture groups (pjd_internal.h): image indices, group after group
+    const uint32_t *iwg_order;           // ... and back-end workgroup indices (into iwgs / marks), group after group
     const uint8_t *ecs;
     uint32_t *words;                     // transposed bitstream words: [wave][PJD_WORD_ROWS][64]
     int16_t *coef;                       // DENSE scratch (exact-kernel path): dense_du * 64 int16, zigzag-slot order
@@ -52,6 +54,9 @@ void pjd_launch_copy_out(hipStream_t s, const void *src, void *dst_mapped, uint6
 void pjd_launch_idct_colour(hipStream_t s, const PjdDevBatch &b, const PjdDevIdctWg *wgs, const uint64_t *dense_base, uint32_t n_wg);
 void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b);                                     // lane-stream input
 void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b);      // three kernels: per-image verdict (status words), local scan, carry
+// one picture group (pjd_internal.h): verdict + DC predictors of its pictures in one launch, then its back-end workgroups
+void pjd_launch_group_dc(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g);
+void pjd_launch_group_idct(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g);
 // ---- stage-level parity (pjd_k_coefdump.hip): coefficients in the reference's MCU_buffer layout; `out` is zeroed by the caller
 void pjd_launch_coefdump_lanes(hipStream_t s, const PjdDevBatch &b, uint32_t image, uint32_t n_iwg, int16_t *out);
 void pjd_launch_coefdump_dense(hipStream_t s, const PjdDevBatch &b, uint32_t image, const int16_t *scratch, uint32_t first_du, uint32_t n_du, int16_t *out);
@@ -64,3 +69,4 @@ void pjd_launch_progressive(hipStream_t s, const PjdDevBatch &b, const uint32_t 
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
 void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b);     // bitstream -> per-lane big-endian words, transposed per wave
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b);     // synchronise + stitch + scan + write
+void pjd_launch_huff_lanes_group(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g, uint32_t group_index);   // the same for one picture group

@@ -436,8 +436,63 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.key > b.key; });
         std::vector<PjdDevHuffWg> ordered;
         ordered.reserve(P.hwgs.size());
-        for (const Unit &u : units) ordered.insert(ordered.end(), P.hwgs.begin() + (long)u.first, P.hwgs.begin() + (long)(u.first + u.count));
+        std::vector<size_t> unit_end;          // positions in the ordered list where a unit ends: no picture straddles them
+        for (const Unit &u : units) {
+            ordered.insert(ordered.end(), P.hwgs.begin() + (long)u.first, P.hwgs.begin() + (long)(u.first + u.count));
+            unit_end.push_back(ordered.size());
+        }
         P.hwgs.swap(ordered);
+        // Picture groups (pjd_internal.h): cut the start order into runs of about equal numbers of waves, densest pictures first.
+        // Only for batches of many small pictures: the group's DC predictors are scanned by one workgroup per picture.
+        // Two groups by default, cut at 30 % of the waves: the first group -- the densest pictures, whose entropy decode ends last -- is
+        // the smaller one, because its back end is what is left to do when the last chain of re-sync rounds has finished.  Measured for
+        // one batch alone (profiles/r04_experiments.md): no groups 2.89 ms, cut at 30 % 2.60, thirds 2.59-2.61, 20/55 % 2.66,
+        // 12/35/65 % 2.67; six groups 4.1 (more streams than the runtime's four hardware queues: chains queue behind each other).
+        // PJD_GROUPS / PJD_GROUP_CUTS ("20,55": percent of the waves) for experiments.
+        uint32_t want = 2;
+        std::vector<uint32_t> cuts_pct = {30};
+        if (const char *e = std::getenv("PJD_GROUPS")) { const int v = std::atoi(e); want = (uint32_t)(v < 1 ? 1 : (v > PJD_MAX_GROUPS ? PJD_MAX_GROUPS : v)); cuts_pct.clear(); }
+        if (const char *e = std::getenv("PJD_GROUP_CUTS")) {
+            cuts_pct.clear();
+            for (const char *q = e; *q;) { cuts_pct.push_back((uint32_t)std::strtoul(q, const_cast<char **>(&q), 10)); while (*q == ',' || *q == ' ') q++; }
+            want = (uint32_t)cuts_pct.size() + 1;
+            if (want > PJD_MAX_GROUPS) { want = PJD_MAX_GROUPS; cuts_pct.resize(PJD_MAX_GROUPS - 1); }
+        }
+        if (cuts_pct.empty()) for (uint32_t k = 1; k < want; k++) cuts_pct.push_back(100u * k / want);
+        bool small = P.fast_images.size() >= 64;
+        for (uint32_t i : P.fast_images) if (P.images[i].n_lane > 8192) small = false;
+        if (small && want > 1) {
+            const size_t total_waves = P.hwaves.size();
+            size_t h0 = 0, waves = 0;
+            std::vector<char> seen(P.images.size(), 0);
+            auto close_group = [&](size_t h1) {
+                PjdDevGroup g;
+                std::memset(&g, 0, sizeof g);
+                g.hwg_first = (uint32_t)h0; g.hwg_count = (uint32_t)(h1 - h0);
+                g.img_first = (uint32_t)P.group_images.size();
+                g.iwg_first = (uint32_t)P.iwg_order.size();
+                for (size_t k = h0; k < h1; k++)
+                    for (uint32_t w = P.hwgs[k].first_wave; w < P.hwgs[k].first_wave + P.hwgs[k].n_waves; w++) {
+                        const uint32_t im = P.hwaves[w].image;
+                        if (seen[im]) continue;
+                        seen[im] = 1;
+                        P.group_images.push_back(im);
+                        for (uint32_t q = 0; q < P.images[im].n_iwg; q++) P.iwg_order.push_back(P.images[im].iwg_base + q);
+                    }
+                g.img_count = (uint32_t)P.group_images.size() - g.img_first;
+                g.iwg_count = (uint32_t)P.iwg_order.size() - g.iwg_first;
+                P.groups.push_back(g);
+                h0 = h1;
+            };
+            size_t pos = 0;
+            for (size_t u = 0; u < unit_end.size(); u++) {
+                for (; pos < unit_end[u]; pos++) waves += P.hwgs[pos].n_waves;
+                const size_t k = P.groups.size();
+                if (k + 1 < want && waves * 100 >= (size_t)cuts_pct[k] * total_waves && u + 1 < unit_end.size()) close_group(pos);
+            }
+            close_group(P.hwgs.size());
+            if (P.groups.size() < 2) { P.groups.clear(); P.group_images.clear(); P.iwg_order.clear(); }
+        }
     }
     // the lane-word kernel copies PJD_WORD_ROWS words from every lane's first byte, whatever the lane's length
     P.ecs_buf_bytes = align_up(ecs_off + PJD_SUB_BYTES_MAX + 64, 256);

@@ -36,6 +36,9 @@ struct PjdPlan {
     std::vector<PjdDevIdctWg> iwgs_dense;  // images routed to the exact kernel up front (dense back end)
     std::vector<PjdDevScan> pscans;        // scans of progressive frames
     std::vector<PjdHostScan> host_scans;   // one per entry of pscans
+    std::vector<PjdDevGroup> groups;       // picture groups (pjd_internal.h); one group: the whole batch in one chain of launches
+    std::vector<uint32_t> group_images;    // image indices, group after group
+    std::vector<uint32_t> iwg_order;       // back-end workgroup indices, group after group
     std::vector<uint32_t> seq_images;      // indices of `sequential` images (progressive frames included)
     std::vector<uint32_t> fast_images;     // the others
     uint64_t ecs_buf_bytes = 0;            // size of the packed bitstream buffer (incl. padding)
