@@ -73,7 +73,7 @@ struct pjd_ctx {
     // picture groups: the chains of groups 1.. run on these, forked from / joined to `stream` (created on first use)
     std::vector<hipStream_t> group_streams;
     std::vector<hipEvent_t> join_ev;
-    hipEvent_t fork_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, tables_ev = nullptr;
 };
 
 #define HIP_TRY(ctx, call)                                                                      \
@@ -218,6 +218,7 @@ void pjd_close(pjd_ctx *ctx)
     for (hipStream_t st : ctx->group_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
     for (hipEvent_t ev : ctx->join_ev) hipEventDestroy(ev);
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
+    if (ctx->tables_ev) hipEventDestroy(ctx->tables_ev);
     ctx->dev_pool.flush([](void *q) { (void)hipFree(q); });
     ctx->pin_pool.flush([](void *q) { (void)hipHostFree(q); });
     delete ctx;
@@ -439,6 +440,7 @@ struct KernelTimer {
 bool ctx_group_streams(pjd_ctx *ctx, size_t ng)
 {
     if (!ctx->fork_ev && hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) != hipSuccess) { ctx->fork_ev = nullptr; return false; }
+    if (!ctx->tables_ev && hipEventCreateWithFlags(&ctx->tables_ev, hipEventDisableTiming) != hipSuccess) { ctx->tables_ev = nullptr; return false; }
     while (ctx->group_streams.size() + 1 < ng) {
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
@@ -465,25 +467,31 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings, bool use_groups)
     pjd_launch_reset(s, b->dev, b->d_status_init, parallel ? b->d_opstate : nullptr, parallel ? b->opstate_bytes / 8 : 0,
                      b->dev.dbg ? (uint32_t)(P.hwaves.size() * 32) : 0u);
     kt.mark("reset");
-    if (parallel || !b->seq_list.empty()) { pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables"); }      // the exact path uses the decode tables too
-    if (parallel) {
-        pjd_launch_lane_words(s, b->dev);    kt.mark("lane_words");
-        const size_t ng = (timings || !use_groups) ? 0 : P.groups.size();       // per-kernel timing: the whole batch in one chain, kernel after kernel
-        if (ng > 1 && ctx_group_streams(ctx, ng)) {
-            // Picture groups (pjd_internal.h): every group's chain entropy decode -> DC predictors -> back end on a stream of its own,
-            // forked from and joined to the context's stream with events (inside a stream capture these become parallel branches of
-            // the graph).  Group 0 holds the densest pictures -- the longest chains of re-sync rounds -- and stays on the main stream.
-            HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, s));
-            for (size_t g = 0; g < ng; g++) {
-                hipStream_t gs = g == 0 ? s : ctx->group_streams[g - 1];
-                if (g) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->fork_ev, 0));
-                pjd_launch_huff_lanes_group(gs, b->dev, P.groups[g], (uint32_t)g);
-                pjd_launch_group_dc(gs, b->dev, P.groups[g]);
-                pjd_launch_group_idct(gs, b->dev, P.groups[g]);
-                if (g) { HIP_TRY(ctx, hipEventRecord(ctx->join_ev[g - 1], gs)); }
-            }
-            for (size_t g = 1; g < ng; g++) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->join_ev[g - 1], 0));
-        } else {
+    const size_t ng = (timings || !use_groups || !parallel) ? 0 : P.groups.size();       // per-kernel timing: the whole batch in one chain, kernel after kernel
+    const bool grouped = ng > 1 && ctx_group_streams(ctx, ng);
+    if (grouped) {
+        // Picture groups (pjd_internal.h): every group's chain bitstream words -> entropy decode -> DC predictors -> back end on a stream
+        // of its own, forked from and joined to the context's stream with events (inside a stream capture these become parallel
+        // branches of the graph).  Group 0 holds the densest pictures -- the longest chains of re-sync rounds -- and stays on the main
+        // stream.  The chains have the same shape on purpose: with the decode tables built on the second stream beside group 0's
+        // bitstream words (a branch one node longer than the other) the graph ran the two entropy decodes one after the other
+        // (4.65 ms instead of 2.60 for a batch alone; profiles/r04_experiments.md).
+        pjd_launch_build_tables(s, b->dev);
+        HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, s));
+        for (size_t g = 0; g < ng; g++) {
+            hipStream_t gs = g == 0 ? s : ctx->group_streams[g - 1];
+            if (g) HIP_TRY(ctx, hipStreamWaitEvent(gs, ctx->fork_ev, 0));
+            pjd_launch_lane_words_group(gs, b->dev, P.groups[g]);
+            pjd_launch_huff_lanes_group(gs, b->dev, P.groups[g], (uint32_t)g);
+            pjd_launch_group_dc(gs, b->dev, P.groups[g]);
+            pjd_launch_group_idct(gs, b->dev, P.groups[g]);
+            if (g) { HIP_TRY(ctx, hipEventRecord(ctx->join_ev[g - 1], gs)); }
+        }
+        for (size_t g = 1; g < ng; g++) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->join_ev[g - 1], 0));
+    } else {
+        if (parallel || !b->seq_list.empty()) { pjd_launch_build_tables(s, b->dev);  kt.mark("build_tables"); }      // the exact path uses the decode tables too
+        if (parallel) {
+            pjd_launch_lane_words(s, b->dev);    kt.mark("lane_words");
             pjd_launch_huff_lanes(s, b->dev);    kt.mark("huff_lanes");
             pjd_launch_lane_dc_scan(s, b->dev);  kt.mark("dc_scan");
             pjd_launch_idct_colour_lanes(s, b->dev);

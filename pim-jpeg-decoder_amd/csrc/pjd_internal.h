@@ -39,14 +39,13 @@
 #endif
 // The cooperative walker (pjd_k_huffman.hip, walk_lane): a re-sync round with at most PjdDevImage::walk_max active lanes is finished
 // by the whole wave taking the lanes one after the other.  A walk has a start-up cost per lane (a window of the bitstream is fetched),
-// a round costs the same whatever the number of lanes, so the threshold is 8 lanes where chains are long -- subsequences shorter than
-// PJD_WALK_DENSE_MCUS MCUs' worth of this picture's stream: lanes rarely merge inside their own subsequence -- and sub_bytes >> PJD_WALK_SHIFT
-// otherwise (4 lanes at 512 bytes: lanes merge early there).  Measured in profiles/r03_experiments.md.  PJD_WALK_MAX in the environment
-// overrides it for every picture of a batch (0: never walk).
-#ifndef PJD_WALK_SHIFT
-#define PJD_WALK_SHIFT     7
-#endif
-#define PJD_WALK_DENSE     8
+// a round costs the same whatever the number of lanes, so the threshold grows with the subsequence: 3 lanes per 512 bytes (6 at 1024),
+// and at least PJD_WALK_DENSE where chains are long -- subsequences shorter than PJD_WALK_DENSE_MCUS MCUs' worth of this picture's
+// stream: lanes rarely merge inside their own subsequence.  Measured in profiles/r03_experiments.md (8 then) and again in round 4 after
+// the second landing pad per lane made rounds shorter: 4 / 6 / 8 / 12 / 16 lanes -> 2.56 / 2.54 / 2.62 / 2.88 / 3.11 ms for a batch alone,
+// no difference with batches in flight.  PJD_WALK_MAX in the environment overrides it for every picture of a batch (0: never walk).
+#define PJD_WALK_LANES(sub_bytes)  (((sub_bytes) * 3u) >> 9)
+#define PJD_WALK_DENSE     6
 #define PJD_WALK_DENSE_MCUS 4
 #define PJD_LUT_BITS       9        // first-level Huffman LUT width
 #define PJD_L2_BITS        (16 - PJD_LUT_BITS)    // a second-level table is indexed by the bits after the prefix

@@ -749,19 +749,20 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
                     const uint32_t sw = wds[k];
                     const bool on = (uint32_t)(2 * k) < cnt;
                     {   // A: ONE path for both kinds of entry (the lanes of a wave stand at DC and AC entries at once): a DC difference
-                        // (slot == 0) is "a coefficient for position 0 with quantiser 1" -- its raw value waits in the tile for the DC stage
+                        // (slot == 0) is an entry with "run + 1" = 1 that lands on position 0 and is DEQUANTISED like any other: the DC
+                        // stage then sums products instead of multiplying the sum -- the same number modulo 2^16, which is all the
+                        // reference keeps (src/jpeg_scanner.cpp:485-486 stores the predictor as a short, src/decoder_dpu.c:169-172 the product)
                         const bool dc = slot == 0;
-                        const uint32_t f = sw & 31u;                        // run + 1; 0: EOB
-                        const uint32_t pos = dc ? 0u : slot + f - 1u;       // an EOB gives slot - 1: stores nothing (below)
-                        if (on && (dc || f != 0) && pos < 64 && u < n_valid) {
+                        const uint32_t f = dc ? 1u : sw & 31u;              // run + 1; 0: EOB
+                        const uint32_t ns = slot + f, pos = ns - 1u;        // an EOB gives slot - 1: stores nothing (below)
+                        if (on && f != 0 && pos < 64 && u < n_valid) {
                             const int val = dc ? (int)(int16_t)(sw & 0xffffu) : (int)(sw << 16) >> 21;
-                            const uint32_t qe = dc ? 1u : qz[comp_of[u]][pos];             // (slot 52 under the quirk: position 64, quantiser 1)
+                            const uint32_t qe = qz[comp_of[u]][pos];        // (slot 52 under the quirk: position 64, quantiser 1)
                             // the low 16 bits of value x quantiser (reference src/decoder_dpu.c:169-172) depend on the low 16 bits of both only
                             pjd_tile_put(tile_lds, u, qe >> 16, pjd_mul_u24((uint32_t)val, qe));
                         }
                         if (on) {
-                            const uint32_t ns = dc ? 1u : slot + f;
-                            const bool last = !dc && (f == 0 || ns > 63);   // EOB, or the entry landed on slot 63 (or past it: a broken stream)
+                            const bool last = f == 0 || ns > 63;            // EOB, or the entry landed on slot 63 (or past it: a broken stream)
                             slot = last ? 0u : ns;
                             u += last ? 1u : 0u;
                         }
@@ -802,7 +803,9 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
         }
     } else {
         const uint32_t d0 = wg.first_mcu * dus;
-        uint32_t cy = pred0[0], cc = (pred0[1] & 0xffffu) | (pred0[2] << 16);   // predictors entering the next group of 64 units
+        // the parser left DEQUANTISED differences: the predictors that enter the range are scaled the same way (all modulo 2^16)
+        const uint32_t q0y = qz[0][0] & 0xffffu, q0b = qz[1][0] & 0xffffu, q0r = qz[2][0] & 0xffffu;
+        uint32_t cy = (pred0[0] * q0y) & 0xffffu, cc = ((pred0[1] * q0b) & 0xffffu) | ((pred0[2] * q0r) << 16);   // predictors entering the next group of 64 units
         for (uint32_t base = 0; base < n_du; base += 64) {
             const uint32_t u = base + lane;
             const bool on = u < n_valid;                        // an undecoded unit keeps DC 0: it is never predicted
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
             else { ty += cy; tc = pjd_op_pkadd(tc, cc); }
             if (on) {
                 const uint32_t dcv = comp == 0 ? ty : (comp == 1 ? tc : tc >> 16);
-                tile[u][0] = (int16_t)pjd_dequant((int)(int16_t)dcv, qz[comp][0] & 0xffffu);
+                tile[u][0] = (int16_t)dcv;
             }
             cy = __shfl(ty, 63); cc = __shfl(tc, 63);
         }

@@ -138,9 +138,17 @@ struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
 
 struct __attribute__((packed)) UnalignedU32x4 { uint32_t v[4]; };
 
-__global__ __launch_bounds__(256) void pjd_k_lane_words(PjdDevBatch B)
+// hwg_count == 0: one block per wave of the batch; else the waves of the Huffman workgroups hwg_first .. (a picture group,
+// pjd_internal.h): two blocks per workgroup.
+__global__ __launch_bounds__(256) void pjd_k_lane_words(PjdDevBatch B, uint32_t hwg_first, uint32_t hwg_count)
 {
-    const uint32_t wv = blockIdx.x;
+    uint32_t wv = blockIdx.x;
+    if (hwg_count) {
+        const PjdDevHuffWg wg = B.hwgs[hwg_first + blockIdx.x / PJD_HUFF_WAVES];
+        const uint32_t k = blockIdx.x % PJD_HUFF_WAVES;
+        if (k >= wg.n_waves) return;
+        wv = wg.first_wave + k;
+    }
     const PjdDevHuffWave hw = B.hwaves[wv];
     const PjdDevImage &im = B.images[hw.image];
     const uint32_t l = threadIdx.x & 63, k0 = threadIdx.x >> 6;
@@ -1433,7 +1441,14 @@ void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b)
 #if PJD_DIRECT_ECS
     return;
 #endif
-    if (b.n_hwave) hipLaunchKernelGGL(pjd_k_lane_words, dim3(b.n_hwave), dim3(256), 0, s, b);
+    if (b.n_hwave) hipLaunchKernelGGL(pjd_k_lane_words, dim3(b.n_hwave), dim3(256), 0, s, b, 0u, 0u);
+}
+void pjd_launch_lane_words_group(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g)
+{
+#if PJD_DIRECT_ECS
+    return;
+#endif
+    if (g.hwg_count) hipLaunchKernelGGL(pjd_k_lane_words, dim3(g.hwg_count * PJD_HUFF_WAVES), dim3(256), 0, s, b, g.hwg_first, g.hwg_count);
 }
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b)
 {

@@ -68,5 +68,6 @@ void pjd_launch_huff_exact_lut(hipStream_t s, const PjdDevBatch &b, const uint32
 void pjd_launch_progressive(hipStream_t s, const PjdDevBatch &b, const uint32_t *image_list, const uint64_t *dense_base, uint32_t n);
 void pjd_launch_build_tables(hipStream_t s, const PjdDevBatch &b);
 void pjd_launch_lane_words(hipStream_t s, const PjdDevBatch &b);     // bitstream -> per-lane big-endian words, transposed per wave
+void pjd_launch_lane_words_group(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g);   // the same for the waves of one picture group
 void pjd_launch_huff_lanes(hipStream_t s, const PjdDevBatch &b);     // synchronise + stitch + scan + write
 void pjd_launch_huff_lanes_group(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g, uint32_t group_index);   // the same for one picture group

@@ -336,7 +336,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             // density of what THIS image (or shard: a slice of the stream for a slice of the MCUs) decodes
             const uint64_t n_mcu_dec = g.last_mcu > g.first_mcu ? g.last_mcu - g.first_mcu : 1;
             const uint64_t bpm = (byte_hi - byte_lo) / n_mcu_dec;                         // bytes of stream per MCU
-            uint32_t wm = SBi >> PJD_WALK_SHIFT;
+            uint32_t wm = PJD_WALK_LANES(SBi);
             if ((uint64_t)SBi <= PJD_WALK_DENSE_MCUS * bpm && wm < PJD_WALK_DENSE) wm = PJD_WALK_DENSE;
             if (walk_max_env >= 0) wm = (uint32_t)(walk_max_env > 64 ? 64 : walk_max_env);
             g.walk_max = (uint8_t)wm;

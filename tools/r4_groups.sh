@@ -13,8 +13,8 @@ v=d['variants']['cfg3lite']
 print('$label', 'in flight', d['value'], d['ms_per_step'], 'serial', d['one_batch_in_flight']['ms_per_step'], '| lite', v['value'], 'serial', v['one_batch_in_flight']['ms_per_step'])"
 }
 run "default (20,55)" A=1
-run "cuts 15,50" PJD_GROUP_CUTS=15,50
-run "cuts 25,60" PJD_GROUP_CUTS=25,60
-run "cuts 12,35,65" PJD_GROUP_CUTS=12,35,65
+
+
+
 run "cuts 30" PJD_GROUP_CUTS=30
 run "groups off" PJD_GROUPS=1
