@@ -455,7 +455,7 @@ def main():
         # (profiles/<tag>_counters.json, written by tools/make_profile.py); only valid for the workload they were collected on
         traffic, valu_issue_frac, prof_src = None, None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_cfg3_counters.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_cfg3_counters.json")))
             if args.workload == tj.get("workload_key") and args.images == 1024:
                 prof_src = tj.get("source")
                 for k, v in tj["per_kernel"].items():

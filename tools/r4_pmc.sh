@@ -5,6 +5,9 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-pmc}; SB=${2:-0}
 OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
 export PJD_SUB_BYTES=$SB
+# the counter passes decode the batch in ONE chain of launches (as with several batches in flight): per-kernel figures are those of
+# whole-batch launches; on an idle device the library issues the same work as two chains (picture groups), traced at the end
+export PJD_GROUPS=1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > "$OUT/counters.txt" 2>&1
 CMD="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 1 --e2e-batches 0 --no-cpu-baseline --no-cli --steps 10"
@@ -17,6 +20,10 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 # kernel trace of the default mode (four batches in flight): which kernels overlap (tools/inflight_overlap.py)
 CMD3="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 4 --e2e-batches 0 --no-cpu-baseline --no-cli --steps 16"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/inflight" -- $CMD3 > "$OUT/inflight.log" 2>&1; echo "inflight rc=$?"
+# one batch alone with the picture groups on (the library's choice on an idle device): which kernels overlap
+unset PJD_GROUPS
+CMD4="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 1 --e2e-batches 0 --no-cpu-baseline --no-cli --steps 10"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/groups" -- $CMD4 > "$OUT/groups.log" 2>&1; echo "groups rc=$?"
 # keep the merge small: the per-dispatch CSVs are enough
 find "$OUT" -name "*.db" -delete
 du -sh "$OUT"
