@@ -357,8 +357,14 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     TRY_RC(dev_alloc(ctx, b->dev.status, (size_t)n_images, tot));
     TRY_RC(dev_alloc(ctx, b->dev.imstate, (size_t)n_images, tot));
     // wave_gen [PJD_GENS][n_hwave], wave_desc [n_hwave] and the ticket live in one allocation, zeroed before every launch
-    TRY_RC(dev_alloc(ctx, b->d_opstate, n_hwave * (PJD_GENS + 1) + 2 + PJD_MAX_GROUPS, tot));      // ... and a ticket per picture group
-    b->opstate_bytes = (n_hwave * (PJD_GENS + 1) + 2 + PJD_MAX_GROUPS) * sizeof(uint64_t);
+    // ... a ticket per picture group, and the pull back end's list, tail and done flags (pjd_internal.h)
+    const size_t op_words = n_hwave * (PJD_GENS + 1) + 2 + PJD_MAX_GROUPS, pull_words = P.iwgs.size() + 2;      // 64-bit words: 2 x n_iwg + 2 dwords
+    TRY_RC(dev_alloc(ctx, b->d_opstate, op_words + pull_words, tot));
+    b->opstate_bytes = (op_words + pull_words) * sizeof(uint64_t);
+    b->dev.ready_tail = reinterpret_cast<uint32_t *>(b->d_opstate + op_words);
+    b->dev.ready_list = b->dev.ready_tail + 2;
+    b->dev.range_done = b->dev.ready_list + P.iwgs.size();
+    b->dev.pull = 0;
     b->dev.wave_gen = b->d_opstate;
     b->dev.wave_desc = b->d_opstate + n_hwave * PJD_GENS;
     b->dev.ticket = reinterpret_cast<uint32_t *>(b->d_opstate + n_hwave * (PJD_GENS + 1));
@@ -467,9 +473,33 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings, bool use_groups)
     pjd_launch_reset(s, b->dev, b->d_status_init, parallel ? b->d_opstate : nullptr, parallel ? b->opstate_bytes / 8 : 0,
                      b->dev.dbg ? (uint32_t)(P.hwaves.size() * 32) : 0u);
     kt.mark("reset");
-    const size_t ng = (timings || !use_groups || !parallel) ? 0 : P.groups.size();       // per-kernel timing: the whole batch in one chain, kernel after kernel
+    // What a decode looks like on an otherwise idle device (use_groups), for a batch of many small pictures (the planner made groups):
+    //   "groups" (default) two chains of launches, dense and light pictures, on two streams
+    //   "pull"   the back end runs BESIDE the entropy decoder and takes pictures as their last wave completes them (pjd_internal.h).
+    //            Bit-exact and complete (the GPU suite passes in this form), but SLOWER: the back end's waves share SIMDs with the
+    //            entropy decoder's chains and stretch them -- 3.4-3.5 ms per batch against 2.6-2.7 for "groups" and 2.9 for "chain"
+    //            (profiles/r04_experiments.md #16); kept as an experiment switch
+    //   "chain"  as with several batches in flight: one chain of launches
+    static const int idle_form = [] { const char *e = std::getenv("PJD_IDLE_FORM"); return !e ? 1 : (!std::strcmp(e, "pull") ? 2 : (!std::strcmp(e, "chain") ? 0 : 1)); }();
+    const bool idle = !timings && use_groups && parallel && !P.groups.empty() && idle_form != 0;       // per-kernel timing: one chain, kernel after kernel
+    const size_t ng = (idle && idle_form == 1) ? P.groups.size() : 0;
     const bool grouped = ng > 1 && ctx_group_streams(ctx, ng);
-    if (grouped) {
+    if (idle && idle_form == 2 && ctx_group_streams(ctx, 2)) {
+        // The pull back end (pjd_internal.h): entropy decode on the context's stream, the back end's pull launch on a second stream
+        // beside it (inside a capture: two parallel one-node branches), then the sweep over whatever the pull launch left.
+        PjdDevBatch dv = b->dev;
+        dv.pull = 1;
+        pjd_launch_build_tables(s, dv);
+        pjd_launch_lane_words(s, dv);
+        HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, s));
+        pjd_launch_huff_lanes(s, dv);
+        hipStream_t s1 = ctx->group_streams[0];
+        HIP_TRY(ctx, hipStreamWaitEvent(s1, ctx->fork_ev, 0));
+        pjd_launch_idct_pull(s1, dv);
+        HIP_TRY(ctx, hipEventRecord(ctx->join_ev[0], s1));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->join_ev[0], 0));
+        pjd_launch_idct_sweep(s, dv);
+    } else if (grouped) {
         // Picture groups (pjd_internal.h): every group's chain bitstream words -> entropy decode -> DC predictors -> back end on a stream
         // of its own, forked from and joined to the context's stream with events (inside a stream capture these become parallel
         // branches of the graph).  Group 0 holds the densest pictures -- the longest chains of re-sync rounds -- and stays on the main

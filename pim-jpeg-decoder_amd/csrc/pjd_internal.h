@@ -126,8 +126,17 @@
 struct PjdDevImState {
     unsigned long long err_key;        // ~0: none
     uint32_t flag_pos;                 // ~0: none
-    uint32_t pad_;
+    uint32_t waves_done;               // Huffman waves of the picture that have finished their write pass (the "pull" back end, below)
 };
+
+// The PULL back end (round 4; the form a decode takes on an otherwise idle device).  With one launch after the other the back end
+// starts when the LAST wave of the entropy decoder has finished although most pictures were complete long before.  Here the last
+// wave of a PICTURE to finish (waves_done reaches the picture's wave count) settles the picture itself -- verdict, DC predictors at
+// its lane starts (what pjd_k_image_verdict / pjd_k_lane_dc_* do) -- and appends the picture's back-end ranges to ready_list; a
+// back-end launch that runs BESIDE the entropy decoder (second stream) takes range k of the list in workgroup k, waiting for the
+// entry to appear (bounded: a workgroup that gives up leaves its range to the sweep -- an ordinary back-end launch that follows
+// and skips the ranges marked done).  All words live in the per-decode operation state (zeroed by pjd_k_reset).
+#define PJD_PULL_SPIN_LIMIT (1u << 12)     // x s_sleep(64): a few milliseconds
 
 // why the parallel decoder flagged an image (PjdDevBatch::stats[PJD_STAT_FLAG0 + reason], counted per wave)
 enum {

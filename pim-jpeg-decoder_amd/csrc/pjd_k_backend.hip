@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void pjd_k_reset(PjdDevBatch B, const int32_t 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < B.n_images) {
         B.status[i] = status_init[i];
-        PjdDevImState st; st.err_key = ~0ull; st.flag_pos = 0xffffffffu; st.pad_ = 0;
+        PjdDevImState st; st.err_key = ~0ull; st.flag_pos = 0xffffffffu; st.waves_done = 0;
         B.imstate[i] = st;
     }
     if (i < 16) B.stats[i] = 0;
@@ -618,20 +618,10 @@ __device__ __forceinline__ void pjd_tile_put(uint32_t tile_lds, uint32_t u, uint
     *reinterpret_cast<__attribute__((address_space(3))) int16_t *>(a) = (int16_t)v;
 }
 
-// order: the launch's workgroup -> index into PjdDevBatch::iwgs / marks (null: the identity, one launch for the whole batch)
-__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdDevBatch B, const uint32_t *__restrict__ order)
+// One back-end range (PjdDevIdctWg `iwg`) by the whole workgroup; the LDS arrays are the kernel's.  Returns are workgroup-uniform.
+__device__ __forceinline__ void pjd_idct_range(const PjdDevBatch &B, uint32_t iwg, int16_t (*tile)[TILE_STRIDE], uint32_t (*qz)[64], uint32_t *mcu_xy,
+                                               uint8_t *comp_of, uint32_t *wagg, uint32_t *ltab)
 {
-    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
-    __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
-    __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
-    __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
-    __shared__ uint32_t wagg[2];              // group parser: groups in the lane window; whether the lane behind the window may belong to the range
-    __shared__ uint32_t ltab[96];             // group parser: the window's lane table
-
-#if PJD_IDCT_PRIO
-    __builtin_amdgcn_s_setprio(PJD_IDCT_PRIO);
-#endif
-    const uint32_t iwg = order ? order[blockIdx.x] : blockIdx.x;
     const PjdDevIdctWg wg = B.iwgs[iwg];
     const PjdDevImage &im = B.images[wg.image];
     if ((im.flags & PJD_IF_SEQUENTIAL) || (B.status[wg.image] & PJD_STW_NEEDS_EXACT)) return;   // the dense path redoes it
@@ -853,15 +843,95 @@ __global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdD
     pjd_colour_dispatch(tile, mcu_xy, B, im, wg, tid);
 }
 
+// order: the launch's workgroup -> index into PjdDevBatch::iwgs / marks (null: the identity, one launch for the whole batch)
+// sweep: only ranges not marked done by the pull launch (pjd_internal.h)
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_colour_lanes(PjdDevBatch B, const uint32_t *__restrict__ order, int sweep)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
+    __shared__ uint32_t qz[3][64];            // per component, by zigzag SLOT: quantiser of its natural position | position << 16
+    __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
+    __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
+    __shared__ uint32_t wagg[2];              // group parser: groups in the lane window; whether the lane behind the window may belong to the range
+    __shared__ uint32_t ltab[96];             // group parser: the window's lane table
+
+#if PJD_IDCT_PRIO
+    __builtin_amdgcn_s_setprio(PJD_IDCT_PRIO);
+#endif
+    const uint32_t iwg = order ? order[blockIdx.x] : blockIdx.x;
+    if (sweep && __hip_atomic_load(B.range_done + iwg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    pjd_idct_range(B, iwg, tile, qz, mcu_xy, comp_of, wagg, ltab);
+}
+
+// The pull launch (pjd_internal.h; experiment switch PJD_IDLE_FORM=pull): a few workgroups per CU stay and take the ranges of ready_list
+// in order -- workgroup w the entries w, w + gridDim.x, ... -- waiting for each to appear.  A kernel of its own: inlined into the
+// kernel above the loop cost it 35 registers (46 -> 81) and with them its occupancy (0.50 -> 0.66 ms, 118 -> 102 GPix/s in flight).
+__global__ __launch_bounds__(PJD_IDCT_THREADS) void pjd_k_idct_pull(PjdDevBatch B)
+{
+    __shared__ __attribute__((aligned(16))) int16_t tile[PJD_IDCT_MAX_DU][TILE_STRIDE];
+    __shared__ uint32_t qz[3][64];
+    __shared__ uint32_t mcu_xy[PJD_IDCT_MAX_DU];
+    __shared__ uint8_t comp_of[PJD_IDCT_MAX_DU];
+    __shared__ uint32_t wagg[2];
+    __shared__ uint32_t ltab[96];
+    // It waits only if every Huffman workgroup has started -- else the device is busy or the launches came in an unlucky order, and
+    // the ranges are left to the sweep.
+    if (threadIdx.x == 0) {
+        uint32_t started = 0;
+        for (uint32_t it = 0; it < 64 && !started; it++) {
+            started = __hip_atomic_load(B.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B.n_hwg ? 1u : 0u;
+            if (!started) __builtin_amdgcn_s_sleep(64);
+        }
+        wagg[1] = started;
+    }
+    __syncthreads();
+    if (wagg[1] == 0) return;
+    for (uint32_t slot = blockIdx.x; slot < B.n_iwg; slot += gridDim.x) {
+        __syncthreads();                                                   // the LDS arrays of the range before
+        if (threadIdx.x == 0) {
+            uint32_t v = 0;
+            for (uint32_t it = 0; it < PJD_PULL_SPIN_LIMIT; it++) {
+                v = __hip_atomic_load(B.ready_list + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            wagg[0] = v;
+        }
+        __syncthreads();
+        const uint32_t v = wagg[0];
+        __syncthreads();
+        if (v == 0) return;                                                // gave up: this entry and the workgroup's later ones go to the sweep
+#if defined(PJD_PULL_EXPERIMENT) && PJD_PULL_EXPERIMENT == 1             // measurement only: take the entry, do nothing (the sweep does the work)
+        continue;
+#endif
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);                           // what the picture's waves wrote (agent scope: other CUs)
+        pjd_idct_range(B, v - 1, tile, qz, mcu_xy, comp_of, wagg, ltab);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(B.range_done + (v - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the sweep: a later launch
+    }
+}
+
 void pjd_launch_idct_colour_lanes(hipStream_t s, const PjdDevBatch &b)
 {
     if (b.n_iwg == 0) return;
-    hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(b.n_iwg), dim3(PJD_IDCT_THREADS), 0, s, b, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(b.n_iwg), dim3(PJD_IDCT_THREADS), 0, s, b, (const uint32_t *)nullptr, 0);
+}
+
+void pjd_launch_idct_pull(hipStream_t s, const PjdDevBatch &b)
+{
+    // two workgroups per CU: enough to keep up with the pictures as they complete, few enough to leave the entropy decoder its issue slots
+    static const uint32_t workers = [] { const char *e = std::getenv("PJD_PULL_WORKERS"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v > 0 ? v : 512); }();
+    const uint32_t n = b.n_iwg < workers ? b.n_iwg : workers;
+    if (n) hipLaunchKernelGGL(pjd_k_idct_pull, dim3(n), dim3(PJD_IDCT_THREADS), 0, s, b);
+}
+
+void pjd_launch_idct_sweep(hipStream_t s, const PjdDevBatch &b)
+{
+    if (b.n_iwg) hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(b.n_iwg), dim3(PJD_IDCT_THREADS), 0, s, b, (const uint32_t *)nullptr, 1);
 }
 
 void pjd_launch_group_idct(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g)
 {
-    if (g.iwg_count) hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(g.iwg_count), dim3(PJD_IDCT_THREADS), 0, s, b, b.iwg_order + g.iwg_first);
+    if (g.iwg_count) hipLaunchKernelGGL(pjd_k_idct_colour_lanes, dim3(g.iwg_count), dim3(PJD_IDCT_THREADS), 0, s, b, b.iwg_order + g.iwg_first, 0);
 }
 
 // ---------------------------------------------------------------------------------------------

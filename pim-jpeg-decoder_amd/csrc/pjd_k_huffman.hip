@@ -972,6 +972,67 @@ __device__ __forceinline__ uint64_t op_wait_flag(const uint64_t *p, bool &timeou
 }
 
 // ---------------------------------------------------------------------------------------------
+// The pull back end (pjd_internal.h): what the LAST wave of a picture to finish does for the picture, with its 64 lanes -- the
+// verdict (pjd_k_image_verdict), the DC predictors at every lane start (pjd_k_lane_dc_local / _carry: a segmented scan over the
+// picture's lanes, here in chunks of 64 with absolute results) -- and the hand-over of the picture's back-end ranges.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void finish_picture(const PjdDevBatch &B, uint32_t image, uint32_t l)
+{
+    const PjdDevImage &im = B.images[image];
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                    // what the picture's other waves wrote
+    if (l == 0) {
+        const int32_t st = B.status[image];
+        if (!(st & PJD_STW_NEEDS_EXACT)) {
+            const PjdDevImState s = B.imstate[image];
+            const bool has_err = s.err_key != ~0ull;
+            const uint32_t err_pos = (uint32_t)(s.err_key >> 32);
+            if (s.flag_pos != 0xffffffffu && (!has_err || s.flag_pos <= err_pos)) B.status[image] = st | PJD_STW_NEEDS_EXACT;
+            else if (has_err) B.status[image] = (int32_t)((s.err_key >> 1) & 7u);
+        }
+    }
+    uint32_t cy = 0, ccb = 0, ccr = 0;                         // predictors entering the current chunk of lanes (wave-uniform)
+    const uint32_t n_lane = rfl(im.n_lane), lane_base = rfl(im.lane_base);
+    for (uint32_t base = 0; base < n_lane; base += 64) {
+        const bool on = base + l < n_lane;
+        uint32_t vy = 0, vcb = 0, vcr = 0, head = 0;
+        if (on) {
+            const PjdDevLaneInfo li = B.lane_info[lane_base + base + l];
+            vy = li.dc_sum[0]; vcb = li.dc_sum[1]; vcr = li.dc_sum[2]; head = li.first_du >> 31;
+        }
+        uint32_t f = head;
+        for (int off = 1; off < 64; off <<= 1) {                // inclusive segmented scan: a lane that starts a restart segment resets
+            const uint32_t ay = __shfl_up(vy, off), acb = __shfl_up(vcb, off), acr = __shfl_up(vcr, off), af = __shfl_up(f, off);
+            if ((int)l >= off) {
+                if (!f) { vy += ay; vcb += acb; vcr += acr; }
+                f |= af;
+            }
+        }
+        // predictors entering this lane: zero at a segment head; else the inclusive result of the lane before it, plus the chunk's
+        // carry-in unless a head lies between the chunk start and this lane
+        const uint32_t py = __shfl_up(vy, 1), pcb = __shfl_up(vcb, 1), pcr = __shfl_up(vcr, 1), pf = __shfl_up(f, 1);
+        if (on) {
+            PjdDevLaneDc d;
+            d.dc_in[0] = d.dc_in[1] = d.dc_in[2] = 0;
+            d.abs = 1;
+            if (!head) {
+                uint32_t qy = cy, qcb = ccb, qcr = ccr;
+                if (l > 0) { qy = (pf ? 0u : cy) + py; qcb = (pf ? 0u : ccb) + pcb; qcr = (pf ? 0u : ccr) + pcr; }
+                d.dc_in[0] = (uint16_t)qy; d.dc_in[1] = (uint16_t)qcb; d.dc_in[2] = (uint16_t)qcr;
+            }
+            B.lane_dc[lane_base + base + l] = d;
+        }
+        const uint32_t ly = __shfl(vy, 63), lcb = __shfl(vcb, 63), lcr = __shfl(vcr, 63), lf = __shfl(f, 63);
+        cy = (lf ? 0u : cy) + ly; ccb = (lf ? 0u : ccb) + lcb; ccr = (lf ? 0u : ccr) + lcr;
+    }
+    __atomic_thread_fence(__ATOMIC_RELEASE);                    // status and predictors before the ranges appear in the list
+    const uint32_t n_iwg = rfl(im.n_iwg), iwg_base = rfl(im.iwg_base);
+    uint32_t base = 0;
+    if (l == 0) base = atomicAdd(B.ready_tail, n_iwg);
+    base = rfl(base);
+    for (uint32_t k = l; k < n_iwg; k += 64) __hip_atomic_store(B.ready_list + base + k, iwg_base + k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The kernel.
 //
 // With one launch per stage every stage waits for the slowest wave of the whole batch, and that wave is
@@ -1040,6 +1101,9 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
     P.build(l);                                                // this wave's phase table (read by this wave only)
     __syncthreads();                                           // the last barrier: from here on waves run on their own
     if (!wave_on) return;
+    // beside the pull back end (pjd_internal.h) every wave of the entropy decoder issues ahead of the back end's: its chains are the
+    // critical path, the back end fills what they leave
+    if (B.pull) __builtin_amdgcn_s_setprio(1);
 
     const uint64_t ts0 = B.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     const uint64_t tc0 = B.dbg ? __builtin_amdgcn_s_memtime() : 0;          // shader clock: with ts0..ts5 (100 MHz) it gives the clock the chip held
@@ -1297,6 +1361,13 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch
         atomicMin(&B.imstate[hw.image].flag_pos, wpos);
         for (int r = 0; r < PJD_FLAG_REASONS; r++)
             if (wflag & (1u << r)) atomicAdd(B.stats + PJD_STAT_FLAG0 + r, 1ull);
+    }
+    if (B.pull) {
+        // the pull back end (pjd_internal.h): the picture's last wave to get here settles the picture and hands its ranges over
+        __atomic_thread_fence(__ATOMIC_RELEASE);                // this wave's entries, lane_info, marks, error state
+        uint32_t done = 0;
+        if (l == 0) done = atomicAdd(&B.imstate[hw.image].waves_done, 1u) + 1u;
+        if (rfl(done) == rfl(im.n_hwave)) finish_picture(B, hw.image, l);
     }
 }
 

@@ -35,6 +35,10 @@ struct PjdDevBatch {
     uint64_t *wave_gen;                  // [PJD_GENS][n_hwave]: exit state of a wave's last lane | flag, one word per generation (pjd_internal.h)
     uint64_t *wave_desc;                 // per Huffman wave: look-back descriptor (status | poison | head | units)
     uint32_t *ticket;                    // workgroup index dispenser
+    uint32_t *ready_list;                // pull back end (pjd_internal.h): [n_iwg] range index + 1 in the order pictures complete; 0: not yet
+    uint32_t *ready_tail;                // entries appended so far
+    uint32_t *range_done;                // [n_iwg] 1: the range's pixels are written
+    uint32_t pull;                       // 1: this launch takes part in the pull protocol (Huffman waves publish, back-end workgroups take from the list)
     uint32_t *dbg;                       // PJD_DEBUG_STATS: per wave, 8 timestamps (10 ns units); else null
     unsigned long long *stats;           // [16] diagnostics: 0 re-sync rounds, 1 lane passes in them, 2 / 3 the same for the stitch
                                          //      stage, PJD_STAT_FLAG0.. waves that flagged their image, by reason, 12 / 13 cooperative walks and the lanes walked in them
@@ -57,6 +61,9 @@ void pjd_launch_lane_dc_scan(hipStream_t s, const PjdDevBatch &b);      // three
 // one picture group (pjd_internal.h): verdict + DC predictors of its pictures in one launch, then its back-end workgroups
 void pjd_launch_group_dc(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g);
 void pjd_launch_group_idct(hipStream_t s, const PjdDevBatch &b, const PjdDevGroup &g);
+// pull back end (pjd_internal.h): the launch that runs beside the entropy decoder, and the sweep over what it left
+void pjd_launch_idct_pull(hipStream_t s, const PjdDevBatch &b);
+void pjd_launch_idct_sweep(hipStream_t s, const PjdDevBatch &b);
 // ---- stage-level parity (pjd_k_coefdump.hip): coefficients in the reference's MCU_buffer layout; `out` is zeroed by the caller
 void pjd_launch_coefdump_lanes(hipStream_t s, const PjdDevBatch &b, uint32_t image, uint32_t n_iwg, int16_t *out);
 void pjd_launch_coefdump_dense(hipStream_t s, const PjdDevBatch &b, uint32_t image, const int16_t *scratch, uint32_t first_du, uint32_t n_du, int16_t *out);
