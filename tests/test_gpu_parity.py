@@ -1144,6 +1144,97 @@ def test_error_in_a_unit_that_runs_on_into_the_next_lane(port, monkeypatch):
         c.close()
 
 
+def test_idle_device_forms_equal_the_single_chain(ctx, port):
+    """A batch of many small pictures decoded on an otherwise idle device is issued as two chains of launches (picture groups:
+    dense and light pictures on two streams); the same batch decoded while another decode of the process is on the device keeps
+    to one chain.  Same pictures, statuses and coefficients either way, also replayed as captured graphs, also with damaged
+    pictures in the batch; and both equal the oracle."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = synth.cfg3_imagenet_like(96, seed=21, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    for k in (5, 40, 77):                      # three damaged streams: an entropy-coding error inside a group
+        ba = bytearray(jpegs[k])
+        body = bytes(ba).rfind(b"\xff\xda") + 14
+        pos = body + (len(ba) - body) // 2
+        while 0xFF in ba[pos - 1:pos + 5]:
+            pos += 1
+        ba[pos:pos + 4] = b"\xff\x00\xff\x00"          # 16 one-bits: a code no table assigns
+        jpegs[k] = bytes(ba)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    assert all(s.valid for s in scanned)
+    descs = [s.desc for s in scanned]
+    want = [port.decode(j) for j in jpegs]
+    other_ctx = pjd_amd.Context(0)
+    try:
+        busy = other_ctx.batch([s.desc for s in scanned[:64]] + [s.desc for s in scanned[:64]], pjd_amd.OUT_BMP)
+        busy.upload()
+        with ctx.batch(descs, pjd_amd.OUT_BMP) as b:
+            b.upload()
+            results = []
+            for graph in (False, True):
+                if graph:
+                    b.capture()
+                    busy.capture()
+                # (1) alone: the library finds the device idle -> picture groups
+                b.decode(); b.sync()
+                outs, st = b.download()
+                results.append(([o.tobytes() for o in outs], list(st), b.coefficients(7).tobytes(), b.coefficients(40).tobytes()))
+                # (2) issued while another batch's decode is in flight -> one chain
+                busy.decode()
+                b.decode()
+                busy.sync(); b.sync()
+                outs, st = b.download()
+                results.append(([o.tobytes() for o in outs], list(st), b.coefficients(7).tobytes(), b.coefficients(40).tobytes()))
+            info = b.info()
+        busy.destroy()
+    finally:
+        other_ctx.close()
+    for r in results[1:]:
+        assert r[1] == results[0][1]
+        assert r[0] == results[0][0]
+        assert r[2:] == results[0][2:]
+    n_err = 0
+    for i, w in enumerate(want):
+        assert results[0][1][i] == w["huff_rc"], i
+        assert results[0][0][i] == w["bmp"], i
+        n_err += w["huff_rc"] != 0
+    assert n_err >= 1 and info["n_fallback"] == 0
+
+
+def test_pull_form_of_the_back_end_is_bit_exact():
+    """PJD_IDLE_FORM=pull (an experiment switch: the back end runs beside the entropy decoder and takes every picture as its last
+    wave completes it; slower than the picture groups on this hardware) stays correct: a batch with dense pictures,
+    restart intervals, every sampling mode and damaged streams against the oracle, in a child process (the switch is read once)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        os.environ["PJD_IDLE_FORM"] = "pull"
+        sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, pjd_amd, oracle_lib, synth
+        port = oracle_lib.Port()
+        jpegs = synth.cfg3_imagenet_like(80, seed=31, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+        jpegs += [synth.make(160, 120, 8, 95, synth.SUB_444, 5), synth.make(201, 77, 9, 50, synth.SUB_422, 0), synth.make(64, 200, 10, 90, synth.SUB_440, 0),
+                  synth.make(99, 99, 11, 75, synth.SUB_GREY, 4)]
+        ba = bytearray(jpegs[3]); k = len(ba) // 2
+        ba[k] = 0x55 if ba[k] != 0x55 else 0x2A
+        jpegs[3] = bytes(ba)
+        sc = [pjd_amd.Scanned(j) for j in jpegs]
+        keep = [i for i, s in enumerate(sc) if s.valid]
+        ctx = pjd_amd.Context(0)
+        b = ctx.batch([sc[i].desc for i in keep], pjd_amd.OUT_RGB8)
+        b.upload(); b.capture()
+        for rep in range(3):
+            b.decode(); b.sync()
+        outs, st = b.download()
+        info = b.info()
+        bad = [i for n, i in enumerate(keep) if st[n] != port.decode(jpegs[i])["huff_rc"] or not np.array_equal(outs[n], port.decode(jpegs[i])["rgb"])]
+        coef_ok = np.array_equal(b.coefficients(1), port.decode(jpegs[keep[1]])["coef"])
+        print("RESULT", "ok" if not bad and coef_ok and info["n_fallback"] == 0 else ("bad %%s coef %%s fb %%s" %% (bad[:5], coef_ok, info["n_fallback"])))
+    """) % (os.path.join(os.path.dirname(HERE), "pim-jpeg-decoder_amd", "python"), HERE, os.path.join(os.path.dirname(HERE), "tools"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RESULT ok" in r.stdout, (r.stdout[-400:] + r.stderr[-400:])
+
+
 # ---- progressive frames (SURVEY 8f N4): not reference-comparable, PARITY UNPINNED ----------------------------------------------
 def test_progressive_decodes_to_the_baseline_twin(ctx, port):
     """The reference cannot decode progressive files (its scanner rejects them, src/jpeg_scanner.cpp:425-430), so nothing of
