@@ -70,22 +70,25 @@
 // the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
 #define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
 // Slots (2 bytes each) of a lane's region.  The write pass emits one 32-bit STEP word per decode step -- one symbol, or the PAIR of
-// symbols one table lookup yields (below) -- and every symbol consumes at least `min_bits` bits of stream: the smallest (code length +
-// value bits) over the Huffman tables of the PICTURE's table set, computed by the planner; 1 if a table has a 1-bit code for a
-// size-0 symbol.  So a lane of `sub_bytes` bytes takes at most 8 * sub_bytes / min_bits steps, plus the symbol that may have
-// started before it and some slack.  (Annex-K tables: 2 bits; optimised tables of dense pictures: 2-4.)
+// symbols one table lookup yields (below).  How many steps a lane of `sub_bytes` bytes can take follows from the PICTURE's table set:
+// the planner computes the fewest bits per step any stream can sustain with it (Annex-K tables: 4 -- a flat unit, DC + EOB, is one
+// step of 4 bits; tables fitted to a dense picture: 4-6; without the DC pairs it was 2).
 // A region is a sequence of 32-byte GROUPS: one head word + PJD_GROUP_STEPS (7) step words (below), a whole number of groups.
 // The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.
 #define PJD_GROUP          16       // slots per group = what the write pass stages between two flushes (8 dwords)
 #define PJD_GROUP_STEPS    (PJD_GROUP / 2 - 1)
-#define PJD_LANE_CAP(sub_bytes, min_bits)   ((((8u * (sub_bytes) + (min_bits) - 1) / (min_bits) + 64u + PJD_GROUP_STEPS - 1) / PJD_GROUP_STEPS + 1u) * PJD_GROUP)
+// step_bits_x256: fewest bits of stream per step the picture's table set can be made to sustain, x 256 (pjd_plan.cpp, min_step_bits_x256:
+// minimum mean cycle of the step graph) -- whole units take at most 8 * sub_bytes * 256 / step_bits_x256 steps; the two units a lane may
+// hold only in part add at most 63 steps each whatever their bits, the symbol that started before the lane and the pair the lane's end
+// breaks a few more.
+#define PJD_LANE_CAP(sub_bytes, step_bits_x256)   ((((8u * (sub_bytes) * 256u + (step_bits_x256) - 1) / (step_bits_x256) + 136u + PJD_GROUP_STEPS - 1) / PJD_GROUP_STEPS + 1u) * PJD_GROUP)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
 // The write pass turns every decoded Huffman symbol into one 16-bit entry; a STEP word holds the one or two entries of a step:
 // low half = entry A, high half = entry B (the second symbol of a pair) or PJD_ENT_NONE.
-//   DC symbol            the step's low half IS the DC difference as int16 (12 significant bits); a DC symbol is never part of a
-//                        pair, the high half is PJD_ENT_NONE.  Which steps hold a DC difference follows from the position: the
-//                        first entry of every data unit.
+//   DC symbol            the step's low half IS the DC difference as int16 (12 significant bits); the high half is the unit's first
+//                        AC symbol where the table holds that pair (short DC symbols: a flat unit, DC + EOB, is ONE step), else
+//                        PJD_ENT_NONE.  Which steps hold a DC difference follows from the position: the first entry of every unit.
 //   AC run/size symbol   bits 15..5 = value (11-bit two's complement; 0 for a size-0 symbol such as ZRL), bits 4..0 = run + 1
 //                        (1..16): the coefficient lands on slot (next free slot + run)
 //   EOB                  0x0000: "run + 1" = 0, value 0 -- completes the unit, stores nothing
@@ -225,9 +228,10 @@ struct PjdDevScan {
 //   pointer entry (bits 4..0 == 0): codes with this 9-bit prefix are longer than 9 bits; bits 15..5 = u16 index (relative to the
 //               blob) / 128 of the prefix's 128-entry second-level table (u16 entries of the form above with code lengths 10..16),
 //               indexed by the following 7 bits.
-// The HIGH half of an L1 entry of an AC table describes the PAIR "this symbol and the one after it" where the 9 bits hold the
-// first symbol whole (code and value bits), it is a valid run/size symbol (not an EOB), and the rest of the 9 bits determine the next code
-// (any valid AC symbol, an EOB too; its value bits may lie outside):
+// The HIGH half of an L1 entry describes the PAIR "this symbol and the one after it" where the 9 bits hold the first symbol whole
+// (code and value bits), it is a valid run/size symbol (not an EOB) or a valid DC symbol, and the rest of the 9 bits determine the next
+// code (any valid AC symbol, an EOB too; its value bits may lie outside) -- for a DC table: a code of the AC table its components
+// decode with (PjdDevTset::pair_ac):
 //   bits 20..16 bits consumed by both symbols (2..27+; 0: no pair here)        bits 27..21 slots both use up (advance 1 + advance 2)
 //   bits 31..28 value bits (size) of the second symbol (its value is the last `size` of the bits both consume)
 // Every pass takes a pair in ONE step when the first symbol neither completes the unit nor reaches the next checkpoint /
@@ -241,6 +245,9 @@ struct PjdDevTset {
     uint16_t l2_off[PJD_MAX_TABLES];   // second-level region of table k: first u16 index, relative to the blob
     uint16_t l2_p0[PJD_MAX_TABLES];    // 9-bit prefixes [p0, p1) hold codes longer than PJD_LUT_BITS
     uint16_t l2_p1[PJD_MAX_TABLES];
+    uint8_t  pair_ac[PJD_MAX_TABLES];  // of a DC table: the AC table (slot) every component that uses it decodes with -- its entries hold the pair
+                                       // "DC symbol + the unit's first AC symbol" -- or 0xff (none: components disagree)
+    uint8_t  pad_[2];
 };
 #define PJD_LUT_USED(e)  ((e) & 31u)
 #define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 96 for an EOB

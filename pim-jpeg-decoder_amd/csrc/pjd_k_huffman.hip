@@ -85,37 +85,44 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
     uint32_t *L1 = reinterpret_cast<uint32_t *>(blob + slot * (PJD_L1_BYTES / 2));
     const uint32_t l2_off = T.l2_off[slot], p0 = T.l2_p0[slot], p1 = T.l2_p1[slot];
     const bool is_ac = r.is_ac != 0;
-    __shared__ uint32_t first[17];
-    __shared__ uint8_t offs[17];
+    // the table the SECOND symbol of a pair is decoded with: this one (AC), or the AC table of the components that use this DC table
+    const uint32_t partner = is_ac ? slot : (uint32_t)T.pair_ac[slot];
+    const bool has_partner = partner < T.n_tables;
+    const PjdDevHuffRaw &r2 = B.raw_tables[(size_t)ts * PJD_MAX_TABLES + (has_partner ? partner : slot)];
+    __shared__ uint32_t first[17], first2[17];
+    __shared__ uint8_t offs[17], offs2[17];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
+    if (tid < 2) {
+        const PjdDevHuffRaw &q = tid ? r2 : r;
+        uint32_t *f = tid ? first2 : first;
         uint32_t code = 0;                       // reference generate_codes (jpeg_scanner.cpp:438-448)
-        first[0] = 0;
+        f[0] = 0;
         for (int len = 1; len <= 16; len++) {
-            first[len] = code;
-            code = (code + (uint32_t)(r.offsets[len] - r.offsets[len - 1])) << 1;
+            f[len] = code;
+            code = (code + (uint32_t)(q.offsets[len] - q.offsets[len - 1])) << 1;
         }
     }
-    if (tid < 17) offs[tid] = r.offsets[tid];
+    if (tid < 17) { offs[tid] = r.offsets[tid]; offs2[tid] = r2.offsets[tid]; }
     __syncthreads();
     // the symbol whose code is the leading bits of `bits` (`nbits` of them are known); 0 if none is determined by them.  Shortest match wins, as the reference's scan
-    auto match = [&](uint32_t bits, uint32_t nbits, uint32_t lo, uint32_t hi) -> uint32_t {
+    auto match_in = [&](const PjdDevHuffRaw &q, const uint32_t *f, const uint8_t *o, bool ac, uint32_t bits, uint32_t nbits, uint32_t lo, uint32_t hi) -> uint32_t {
         for (uint32_t len = lo; len <= hi && len <= nbits; len++) {
             const uint32_t c = bits >> (nbits - len);
-            const uint32_t d = c - first[len], cnt = (uint32_t)offs[len] - offs[len - 1];
-            if (c >= first[len] && d < cnt) return lut_entry(len, r.symbols[offs[len - 1] + d], is_ac);
+            const uint32_t d = c - f[len], cnt = (uint32_t)o[len] - o[len - 1];
+            if (c >= f[len] && d < cnt) return lut_entry(len, q.symbols[o[len - 1] + d], ac);
         }
         return 0u;
     };
+    auto match = [&](uint32_t bits, uint32_t nbits, uint32_t lo, uint32_t hi) -> uint32_t { return match_in(r, first, offs, is_ac, bits, nbits, lo, hi); };
     for (uint32_t idx = tid; idx < (1u << PJD_LUT_BITS); idx += 256) {
         uint32_t e = (idx >= p0 && idx < p1) ? (((l2_off + ((idx - p0) << PJD_L2_BITS)) >> PJD_L2_BITS) << 5) : LUT_BAD;      // pointer entry: bits 4..0 == 0
         const uint32_t m = match(idx, PJD_LUT_BITS, 1, PJD_LUT_BITS);
         if (m) e = m;
-        // the pair: this symbol whole inside the 9 bits, a valid run/size symbol, and the bits after it determine the next code
+        // the pair: this symbol whole inside the 9 bits, a valid run/size (or DC) symbol, and the bits after it determine the next code
         uint32_t pair = 0;
-        if (is_ac && m && !(m & PJD_LUT_EOB) && PJD_LUT_SIZE(m) < PJD_LUT_BADSYM && PJD_LUT_USED(m) < PJD_LUT_BITS) {
+        if (has_partner && m && !(m & PJD_LUT_EOB) && PJD_LUT_SIZE(m) < PJD_LUT_BADSYM && PJD_LUT_USED(m) < PJD_LUT_BITS) {
             const uint32_t rest = PJD_LUT_BITS - PJD_LUT_USED(m);
-            const uint32_t m2 = match(idx & ((1u << rest) - 1u), rest, 1, rest);
+            const uint32_t m2 = match_in(r2, first2, offs2, true, idx & ((1u << rest) - 1u), rest, 1, rest);
             if (m2 && PJD_LUT_SIZE(m2) < PJD_LUT_BADSYM && PJD_LUT_USED(m) + PJD_LUT_USED(m2) <= 31u)
                 pair = (PJD_LUT_USED(m) + PJD_LUT_USED(m2)) | ((PJD_LUT_ADV(m) + PJD_LUT_ADV(m2)) << 5) | (PJD_LUT_SIZE(m2) << 12);   // size 2: bits 31..28 of the entry
         }
@@ -720,7 +727,7 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
 // bitstream before the picture is complete.  It stops AT the offending symbol exactly as decode_MCU_component does
 // (reference src/jpeg_scanner.cpp:469-518): nothing of that symbol is stored, everything before it is; an error inside a unit's
 // AC part leaves the unit with what it has (closed here by an end-of-block entry), an error in the DC symbol leaves the unit
-// untouched.  Rare by construction, so every symbol is a step word of its own, written straight to HBM.
+// untouched.  Rare by construction: step words go straight to HBM, two symbols to a word wherever the first leaves its unit open.
 //   eof_rel: bits from the lane's first byte to the end of the stream, or ~0 if the stream does not end in this lane's segment:
 //            running out of bits is get_next_symbol's 0xFF / read_bits' -1 (reference src/headers/jpeg.h:91-113)
 struct Careful {
@@ -745,18 +752,25 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
     int zb = 63 - (int)z;
     R.n = 0; R.cls = 0; R.p_err = 0; R.D_err = 0; R.in_dc = 0; R.dcA = 0; R.dcB = 0;
     const bool at_end = eof_rel != 0xffffffffu;
+    // A symbol that leaves its unit open waits one turn in its step word: the symbol after it (an AC symbol of the same unit) joins it
+    // as entry B.  Never more steps than the fast pass takes for the same symbols (its pairs are a subset of these), which is what the
+    // lane's region is sized for.
+    bool open = false;                                                           // the last step word written has its B half free
+    uint32_t open_at = 0, open_ent = 0;
     while (D < D_end && (p < end_bit || at_end)) {
         const bool is_dc = zb == 63;
-        if ((R.n & (PJD_GROUP - 1)) == 0 && R.n + 2 <= cap) {                    // a group begins: its head (pjd_internal.h)
-            region32[R.n >> 1] = ((D - D_in) << 8) | (63u - (uint32_t)zb);
-            R.n += 2;
-        }
-        if (is_dc && D == R.mark_D) {                                            // this unit opens an IDCT workgroup's range (as write_step)
-            PjdDevMark m;
-            m.lane = R.lane_q; m.ent_off = R.n;
-            m.acc[0] = (uint16_t)R.dcA; m.acc[1] = (uint16_t)(R.dcA >> 16); m.acc[2] = (uint16_t)R.dcB; m.pad_ = 0;
-            R.marks[R.mark_next++] = m;
-            R.mark_D += R.ru;
+        if (!open) {
+            if ((R.n & (PJD_GROUP - 1)) == 0 && R.n + 2 <= cap) {                // a group begins: its head (pjd_internal.h)
+                region32[R.n >> 1] = ((D - D_in) << 8) | (63u - (uint32_t)zb);
+                R.n += 2;
+            }
+            if (is_dc && D == R.mark_D) {                                        // this unit opens an IDCT workgroup's range (as write_step)
+                PjdDevMark m;
+                m.lane = R.lane_q; m.ent_off = R.n;
+                m.acc[0] = (uint16_t)R.dcA; m.acc[1] = (uint16_t)(R.dcA >> 16); m.acc[2] = (uint16_t)R.dcB; m.pad_ = 0;
+                R.marks[R.mark_next++] = m;
+                R.mark_D += R.ru;
+            }
         }
         const uint32_t pk = w.peek();
         const uint4 nx = lds_u32x4(cur.y);
@@ -776,7 +790,11 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
         }
         if (bad) {
             R.cls = bad; R.p_err = p; R.D_err = D; R.in_dc = is_dc ? 1u : 0u;
-            if (!is_dc && R.n + 2 <= cap) { region32[R.n >> 1] = PJD_ENT_EOB | (PJD_ENT_NONE << 16); R.n += 2; }   // the unit keeps what it has (its group head, if it opens a group, was written above)
+            // the unit keeps what it has: an EOB closes it (its group head, if it opens a group, was written above)
+            if (!is_dc) {
+                if (open) region32[open_at] = open_ent | (PJD_ENT_EOB << 16);
+                else if (R.n + 2 <= cap) { region32[R.n >> 1] = PJD_ENT_EOB | (PJD_ENT_NONE << 16); R.n += 2; }
+            }
             break;
         }
         const int val = jpeg_extend(__builtin_amdgcn_ubfe(pk, 32u - used, size), size);
@@ -785,7 +803,12 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
         zb -= (int)adv;
         const bool done = zb < 0;
         const uint32_t ent = is_dc ? ((uint32_t)val & 0xffffu) : ((((uint32_t)val << 5) | (adv & 31u)) & 0xffffu);
-        if (R.n + 2 <= cap) { region32[R.n >> 1] = ent | (PJD_ENT_NONE << 16); R.n += 2; }
+        if (open) { region32[open_at] = open_ent | (ent << 16); open = false; }
+        else if (R.n + 2 <= cap) {
+            region32[R.n >> 1] = ent | (PJD_ENT_NONE << 16);
+            open = !done; open_at = R.n >> 1; open_ent = ent;
+            R.n += 2;
+        }
         const uint32_t dv = is_dc ? ((uint32_t)val & 0xffffu) : 0u, dvv = dv | (dv << 16);
         R.dcA = pk_add16(R.dcA, dvv & cur.z);
         R.dcB = pk_add16(R.dcB, dvv & cur.w);

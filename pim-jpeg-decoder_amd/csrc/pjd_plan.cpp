@@ -37,6 +37,75 @@ extern "C" uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_for
     return (uint64_t)width * height * 3;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fewest bits of stream per STEP of the write pass that a table set can be made to sustain (x 256) -- what sizes the lane regions.
+// A step is one symbol or the pair the decode tables hold (pjd_internal.h): first symbol whole inside 9 bits (code + value bits, at
+// most 8), the second symbol's code inside the rest.  Model: a graph whose edges are steps weighted by the bits they consume --
+//   node D   the next symbol is a unit's DC symbol            node A_L   the next symbol is an AC symbol with a code of >= L bits
+// (a symbol that stayed single because the code after it did not fit the 9 bits leaves that code, which is long, for the next step);
+// every unit is a cycle through D, so over whole units bits >= steps x (minimum mean weight of a cycle): Karp's algorithm on 17 nodes.
+// A unit may also end on any run/size symbol (it fills slot 63), which the graph allows everywhere: conservative.
+// `combos`: the (DC table, AC table, DC pairs allowed) of the components.
+struct SymBits { uint32_t len, bits; bool eob; };
+static std::vector<SymBits> table_symbols(const pjd_huff_table &t, bool ac)
+{
+    std::vector<SymBits> v;
+    for (int len = 1; len <= 16; len++)
+        for (uint32_t q = t.offsets[len - 1]; q < t.offsets[len] && q < 162; q++) {
+            const uint32_t sym = t.symbols[q];
+            if (sym == 0xFF) continue;                                       // the reference's "no symbol": decoding stops there
+            if (ac ? ((sym & 15u) > 10) : (sym > 11)) continue;              // out-of-range size: an error, decoding stops there
+            v.push_back({(uint32_t)len, (uint32_t)len + (ac ? (sym & 15u) : sym), ac && sym == 0});
+        }
+    return v;
+}
+static uint32_t min_step_bits_x256(const std::vector<std::pair<const pjd_huff_table *, const pjd_huff_table *>> &combos, const std::vector<char> &dc_pairs)
+{
+    const int V = 17;                                    // 0: D, L = 1..16: A_L
+    const uint32_t INF = 1u << 30;
+    std::vector<uint32_t> w((size_t)V * V, INF);
+    auto edge = [&](int u, int v, uint32_t bits) { if (bits < w[(size_t)u * V + v]) w[(size_t)u * V + v] = bits; };
+    // the code after a symbol that stayed single is at least this long (a pair broken for another reason -- the lane ends -- happens once
+    // per lane: PJD_LANE_CAP's slack)
+    auto need = [](uint32_t first_bits) { return first_bits >= 9 ? 1 : (int)(10 - first_bits); };
+    for (size_t c = 0; c < combos.size(); c++) {
+        const std::vector<SymBits> dc = table_symbols(*combos[c].first, false), ac = table_symbols(*combos[c].second, true);
+        for (const SymBits &x : dc) {
+            edge(0, dc_pairs[c] ? need(x.bits) : 1, x.bits);
+            if (dc_pairs[c] && x.bits <= 8)
+                for (const SymBits &y : ac)
+                    if (x.bits + y.len <= 9) { edge(0, y.eob ? 0 : 1, x.bits + y.bits); edge(0, 0, x.bits + y.bits); }
+        }
+        for (int L = 1; L <= 16; L++)
+            for (const SymBits &y : ac) {
+                if ((int)y.len < L) continue;
+                if (y.eob) { edge(L, 0, y.bits); continue; }
+                edge(L, 0, y.bits);                                          // fills slot 63: the unit ends
+                edge(L, need(y.bits), y.bits);                               // stays single: the next code is long
+                if (y.bits <= 8)
+                    for (const SymBits &z : ac)
+                        if (y.bits + z.len <= 9) { edge(L, z.eob ? 0 : 1, y.bits + z.bits); edge(L, 0, y.bits + z.bits); }
+            }
+    }
+    // Karp: minimum mean cycle.  dist[k][v] = lightest walk of exactly k edges from anywhere to v
+    std::vector<std::vector<uint64_t>> dist(V + 1, std::vector<uint64_t>(V, (uint64_t)1 << 40));
+    for (int v = 0; v < V; v++) dist[0][v] = 0;
+    for (int k = 1; k <= V; k++)
+        for (int u = 0; u < V; u++)
+            for (int v = 0; v < V; v++)
+                if (w[(size_t)u * V + v] < INF && dist[k - 1][u] + w[(size_t)u * V + v] < dist[k][v]) dist[k][v] = dist[k - 1][u] + w[(size_t)u * V + v];
+    double best = 1e9;
+    for (int v = 0; v < V; v++) {
+        if (dist[V][v] >= ((uint64_t)1 << 40)) continue;
+        double worst = -1e9;
+        for (int k = 0; k < V; k++)
+            if (dist[k][v] < ((uint64_t)1 << 40)) worst = std::max(worst, (double)((int64_t)dist[V][v] - (int64_t)dist[k][v]) / (double)(V - k));
+        best = std::min(best, worst);
+    }
+    if (best > 64.0 || best < 1.0) best = best < 1.0 ? 1.0 : 64.0;
+    return (uint32_t)(best * 256.0);                    // rounded down
+}
+
 int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &P, std::string &err,
                   uint32_t sub_bytes_override)
 {
@@ -87,6 +156,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     std::map<std::string, uint32_t> tset_of;       // raw bytes of a deduplicated table list -> table set
     std::vector<char> tset_parallel;               // per set: the two-level tables fit the parallel decoder
     std::vector<uint32_t> tset_min_bits;           // per set: fewest bits (code + value bits) any of its symbols consumes
+    std::vector<uint32_t> tset_step_bits;          // per set: fewest bits per step of the write pass, x 256 (min_step_bits_x256)
     uint64_t ent_off = 0;                          // slots of the lane regions handed out so far
     for (int i = 0; i < n; i++) {
         const pjd_image_desc &d = images[i];
@@ -178,13 +248,27 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                 if (sl < 0) { sl = nt++; seen[sl] = t; seen_ac[sl] = (uint8_t)a; }
                 g.tbl_slot[c][a] = (uint8_t)sl;
             }
+        // of a DC table: the AC table every component that uses it decodes with (the tables then hold the pair "DC symbol + first AC symbol")
+        uint8_t pair_ac[PJD_MAX_TABLES];
+        std::memset(pair_ac, 0xff, sizeof pair_ac);
+        {
+            bool clash[PJD_MAX_TABLES] = {false};
+            for (int c = 0; c < (int)g.ncomp && !progressive; c++) {
+                const uint8_t dslot = g.tbl_slot[c][0], aslot = g.tbl_slot[c][1];
+                if (pair_ac[dslot] == 0xff && !clash[dslot]) pair_ac[dslot] = aslot;
+                else if (pair_ac[dslot] != aslot) { clash[dslot] = true; pair_ac[dslot] = 0xff; }
+            }
+        }
         std::string key;
-        key.reserve((size_t)nt * 180);
+        key.reserve((size_t)nt * 180 + 8);
         for (int k = 0; k < nt; k++) {
             key.push_back((char)seen_ac[k]);
             key.append(reinterpret_cast<const char *>(seen[k]->offsets), 17);
             key.append(reinterpret_cast<const char *>(seen[k]->symbols), 162);
         }
+        // the components' assignment belongs to the set: it decides which DC tables hold pairs and how many steps a lane can take
+        key.push_back((char)g.ncomp);
+        for (int c = 0; c < (int)g.ncomp; c++) { key.push_back((char)g.tbl_slot[c][0]); key.push_back((char)g.tbl_slot[c][1]); }
         auto found = tset_of.find(key);
         if (progressive) found = tset_of.end();                 // no table set: the scans bring their tables
         else if (found == tset_of.end()) {
@@ -227,6 +311,16 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
                 T.l2_off[k] = (uint16_t)(lut_bytes / 2);
                 lut_bytes += (p1 - p0) * (2u << PJD_L2_BITS);
                 if (lut_bytes > PJD_LUT_LDS_MAX) ok = false;
+            }
+            std::memcpy(T.pair_ac, pair_ac, sizeof pair_ac);
+            {
+                std::vector<std::pair<const pjd_huff_table *, const pjd_huff_table *>> combos;
+                std::vector<char> dcp;
+                for (int c = 0; c < (int)g.ncomp; c++) {
+                    combos.push_back({&d.dc[d.comp_dc[c]], &d.ac[d.comp_ac[c]]});
+                    dcp.push_back(pair_ac[g.tbl_slot[c][0]] == g.tbl_slot[c][1] ? 1 : 0);
+                }
+                tset_step_bits.push_back(min_step_bits_x256(combos, dcp));
             }
             T.lut_bytes = ok ? (uint32_t)align_up(lut_bytes, 16) : 0;
             T.lut_off16 = (uint32_t)(lut_off / 16);
@@ -367,7 +461,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             g.n_seg = (uint32_t)P.segs.size() - g.seg_base;
             g.n_lane = (uint32_t)P.subs.size() - g.lane_base;
             // lane regions of this picture: sized by ITS subsequence and the cheapest symbol of ITS tables (pjd_internal.h)
-            g.lane_cap = PJD_LANE_CAP(SBi, tset_min_bits[g.tset]);
+            g.lane_cap = PJD_LANE_CAP(SBi, tset_step_bits[g.tset]);
             g.ent_base = ent_off;
             ent_off += (uint64_t)g.n_lane * g.lane_cap;
             if (g.lane_cap > P.lane_cap) P.lane_cap = g.lane_cap;

@@ -546,3 +546,121 @@ void sim_quanta(const Sim *s, int S, int nchk, int use_b, long *out)
     out[2] = nw;
     free(ex); free(A); free(Bc); free(M); free(wq);
 }
+
+// One WAVE at a time (64 lanes, the first lane's entry is the true state), as the GPU runs it: the speculative pass, rounds while more
+// than walk_max lanes are active (a round lasts as long as its longest decode), then the walk (chains one after the other, WALK_COST of a
+// lane's time per byte, a changed exit carried into the next lane).  Landing pads at checkpoint 1: A (newest trajectory, all checkpoints),
+// B (the one before), and with nhyp > 0 up to two HYPOTHESES (start phases 2 and 4, or 1 and 2 for three-unit MCUs) decoded for the
+// lanes that are active in a round with room for helpers (active <= 21, from the second round on): free, the round is a full pass anyway.
+// out[0] = sum over waves of time (bytes of lane-decode equivalents), out[1] = slowest wave, out[2] = waves, out[3] = rounds, out[4] = lanes walked,
+// out[5] = walked bytes, out[6] = merges into a hypothesis
+#define WALK_COST 0.2
+typedef struct { St st; St exit; int valid; } Pad;
+static int st_eq(St a, St b) { return a.p == b.p && a.z == b.z && a.c == b.c; }
+// decode lane k from `in` until it meets a landing pad or the end; returns the exit, *len = bytes decoded, updates A (and B by the swap rule)
+static St lane_pass(const Sim *s, int S, int nchk, long lane0_bit, St in, Traj *A, St *cur_exit, Pad *B, Pad *H, int nh, long *len, long *hypm)
+{
+    const long start_bit = lane0_bit, end_bit = lane0_bit + (long)S * 8, span = (long)S * 8 / nchk;
+    long ndu = 0, next = start_bit + span; int j = 1;
+    const long p0 = in.p;
+    Traj rec; rec.nchk = 0;
+    St e; int done = 0;
+    const St oldA1 = A->chk[0]; const int oldA_has1 = A->nchk >= 1; const St old_exit = *cur_exit;
+    while (in.p < end_bit && in.p < s->nbits && !done) {
+        if (step(s, &in.p, &in.z, &in.c, &ndu, 1)) break;
+        if (in.p >= next && j < nchk && in.p < end_bit) {
+            if (A->nchk >= j && st_eq(A->chk[j - 1], in)) { for (int q = j - 1; q < A->nchk; q++) rec.chk[q] = A->chk[q]; rec.nchk = A->nchk; e = A->exit; done = 1; break; }
+            if (j == 1) {
+                if (B->valid && st_eq(B->st, in)) { rec.chk[0] = in; rec.nchk = 1; e = B->exit; done = 2; break; }
+                for (int h = 0; h < nh && !done; h++) if (H[h].valid && st_eq(H[h].st, in)) { rec.chk[0] = in; rec.nchk = 1; e = H[h].exit; done = 3; (*hypm)++; }
+                if (done) break;
+            }
+            rec.chk[j - 1] = in; rec.nchk = j; j++; next += span;
+        }
+    }
+    if (!done) e = in;
+    *len = (in.p - p0) / 8;
+    rec.exit = e;
+    if (oldA_has1 && rec.nchk >= 1 && !st_eq(rec.chk[0], oldA1)) { B->st = oldA1; B->exit = old_exit; B->valid = 1; }
+    *A = rec;
+    return e;
+}
+void sim_waves(const Sim *s, int S, int nchk, int walk_max, int nhyp, double *out)
+{
+    const long nbytes = s->nbits / 8;
+    const int nl = (int)((nbytes + S - 1) / S);
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    for (int w0 = 0; w0 < nl; w0 += 64) {
+        const int n = nl - w0 < 64 ? nl - w0 : 64;
+        St ex[64]; Traj A[64]; Pad B[64]; Pad H[64][2]; uint8_t chg[65], nchg[65];
+        memset(B, 0, sizeof B); memset(H, 0, sizeof H);
+        int dummy = 0; long len;
+        double t = 0;
+        for (int k = 0; k < n; k++) {
+            St in = { (long)(w0 + k) * S * 8, 0, 0 };
+            ex[k] = run_lane_merge(s, in, in.p, in.p + (long)S * 8, nchk, A + k, 0, 1, &len, &dummy, A + k);
+            chg[k] = 1;
+        }
+        t += S;                                                   // the speculative pass
+        // the true entry of the wave's first lane
+        St truth0; { long p = (long)w0 * S * 8; while (p < s->nbits && !s->tz[p]) p++; truth0.p = p; truth0.z = s->tz[p] ? s->tz[p] - 1 : 0; truth0.c = s->tc[p]; }
+        int first = 1;
+        for (int round = 1; round < 200; round++) {
+            int act[64], na = 0;
+            for (int k = 0; k < n; k++) { const int a = k == 0 ? (first && w0 > 0) : chg[k - 1]; if (a) act[na++] = k; }
+            first = 0;
+            if (!na) break;
+            out[3]++;
+            memset(nchg, 0, sizeof nchg);
+            if (na <= walk_max) {
+                // the walk: chains one after the other
+                uint8_t pending[64] = {0};
+                for (int i = 0; i < na; i++) pending[act[i]] = 1;
+                for (int k = 0; k < n; k++) {
+                    if (!pending[k]) continue;
+                    int a = k;
+                    for (;;) {
+                        pending[a] = 0;
+                        const St in = a == 0 ? truth0 : ex[a - 1];
+                        const St e = lane_pass(s, S, nchk, (long)(w0 + a) * S * 8, in, A + a, ex + a, B + a, H[a], nhyp, &len, (long *)&dummy);
+                        out[4]++; out[5] += len; t += len * WALK_COST + 0.03 * S * WALK_COST * 5;   // + a start-up cost per walked lane (~2 us)
+                        if (st_eq(e, ex[a])) break;
+                        ex[a] = e;
+                        if (a + 1 >= n) break;
+                        a++;
+                    }
+                }
+                break;
+            }
+            long longest = 0;
+            St nex[64]; memcpy(nex, ex, sizeof nex);
+            long hm = 0;
+            for (int i = 0; i < na; i++) {
+                const int k = act[i];
+                const St in = k == 0 ? truth0 : ex[k - 1];
+                const St e = lane_pass(s, S, nchk, (long)(w0 + k) * S * 8, in, A + k, ex + k, B + k, H[k], nhyp, &len, &hm);
+                if (len > longest) longest = len;
+                if (!st_eq(e, ex[k])) { nex[k] = e; nchg[k] = 1; }
+            }
+            out[6] += hm;
+            if (nhyp && round >= 2 && na * nhyp + na <= 64) {
+                // helpers: idle lanes decode the active lanes' subsequences from their first bit under other start phases
+                for (int i = 0; i < na; i++) {
+                    const int k = act[i];
+                    for (int h = 0; h < nhyp; h++) {
+                        if (H[k][h].valid) continue;
+                        St in = { (long)(w0 + k) * S * 8, 0, (s->dus >= 6 ? 2 + 2 * h : 1 + h) % s->dus };
+                        Traj tt; tt.nchk = 0; Traj none; none.nchk = 0;
+                        St e = run_lane_merge(s, in, in.p, in.p + (long)S * 8, nchk, &none, 0, 1, &len, &dummy, &tt);
+                        if (tt.nchk >= 1) { H[k][h].st = tt.chk[0]; H[k][h].exit = e; H[k][h].valid = 1; }
+                    }
+                }
+                longest = S;
+            }
+            memcpy(ex, nex, sizeof nex);
+            memcpy(chg, nchg, sizeof chg);
+            t += longest;
+        }
+        out[0] += t; if (t > out[1]) out[1] = t; out[2]++;
+    }
+}
