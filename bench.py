@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4,
                     help="resident batches decoded round-robin, each on its own HIP stream: step i is issued while step i-1 is "
                          "still running, as a serving loop would (1 = strictly one step after the other)")
+    ap.add_argument("--plan-mode", default="auto", choices=["auto", "latency", "throughput"],
+                    help="pjd_set_plan_mode of the contexts: auto = throughput for the batches kept in flight, latency for the batch that is "
+                         "decoded alone (one_batch_in_flight, kernels_ms, roofline)")
     ap.add_argument("--force-exact", action="store_true",
                     help="decode everything with the exact one-lane kernel (PJD_F_FORCE_SEQUENTIAL): the bound of the fallback path, not a product mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -344,7 +347,11 @@ def main():
                 s.desc.flags = int(s.desc.flags) | pjd_amd.F_STANDARD_RESTART
         # One context = one HIP stream.  `--in-flight` identical batches are resident; step i decodes batch i % in_flight,
         # so consecutive steps overlap (the slow tail of one step's entropy decode runs beside the next step's bulk).
-        ctxs = [pjd_amd.Context(local_rank) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing
+        # Batches kept in flight are planned for pictures per second, a batch decoded alone for its own latency (include/pjd.h,
+        # pjd_set_plan_mode: how much stream an entropy-decoder lane takes); --plan-mode overrides both.
+        mode_of = {"latency": pjd_amd.PLAN_LATENCY, "throughput": pjd_amd.PLAN_THROUGHPUT}
+        main_mode = mode_of.get(args.plan_mode, pjd_amd.PLAN_THROUGHPUT if nfl > 1 else pjd_amd.PLAN_LATENCY)
+        ctxs = [pjd_amd.Context(local_rank, plan_mode=main_mode) for _ in range(nfl)]      # raises if the HIP library / a gfx950 device is missing
         batches = [c.batch(descs, out_fmt) for c in ctxs]
         batch = batches[0]
         t_up = time.perf_counter()
@@ -374,13 +381,24 @@ def main():
             r["host_ms"]["distribute"] = round(t_dist * 1e3, 1)
             r["split_info"] = split_info
         # the same K steps strictly one after the other (reported beside `value`, never instead of it)
+        r["info"] = batch.info()
+        alone = batch                 # the batch that is decoded ALONE: planned for latency
         if nfl > 1:
+            alone_mode = mode_of.get(args.plan_mode, pjd_amd.PLAN_LATENCY)
+            if alone_mode != main_mode:
+                ctxs.append(pjd_amd.Context(local_rank, plan_mode=alone_mode))
+                alone = ctxs[-1].batch(descs, out_fmt)
+                batches.append(alone)
+                alone.upload()
+                if not args.no_graph:
+                    alone.capture()
+                run_steps(2, [alone])
             barrier()
             t0 = time.perf_counter()
-            run_steps(steps, batches[:1])
+            run_steps(steps, [alone])
             barrier()
             r["dt_serial"] = time.perf_counter() - t0
-        r["info"] = batch.info()
+            r["info_alone"] = alone.info()
         # whole-job totals: ranks decode different seeded batches, so sum what each one really processed per step
         tot = [float(r["info"]["pixels"]), float(r["info"]["ecs_bytes"]), float(r["info"]["n_entries"])]
         if world > 1 and not split:
@@ -392,8 +410,8 @@ def main():
             # per-kernel durations, HIP events on the library's own stream (ungraphed launches of the same work)
             ktimes, ktotal, reps = {}, 0.0, 5
             for _ in range(reps):
-                kt, tot = batch.decode_timed()
-                batch.sync()
+                kt, tot = alone.decode_timed()
+                alone.sync()
                 for k, v in kt.items():
                     ktimes[k] = ktimes.get(k, 0.0) + v / reps
                 ktotal += tot / reps
@@ -428,8 +446,12 @@ def main():
              "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
              "exact_kernel_images": info["n_sequential"] + info["n_fallback"]}
         if "dt_serial" in r:
+            ia = r["info_alone"]
             o["one_batch_in_flight"] = {"value": round(mult * info["pixels"] * k / r["dt_serial"] / 1e6, 2), "unit": "MPix/s",
-                                        "ms_per_step": round(r["dt_serial"] / k * 1e3, 4)}
+                                        "ms_per_step": round(r["dt_serial"] / k * 1e3, 4),
+                                        "plan_mode": "throughput" if ia["plan_mode"] else "latency",
+                                        "huffman_lanes": ia["n_subsequences"], "sub_bytes": ia["sub_bytes"], "huffman_waves": ia["n_huff_waves"],
+                                        "lane_passes_per_lane": round(2.0 + ia["sync_lane_passes"] / max(1, ia["n_subsequences"]), 3)}
         return o
 
     R = measure(args.workload, args.steps, args.warmup, True)
@@ -467,7 +489,8 @@ def main():
         line = {
             "metric": "MPixels/sec JPEG->RGB (bit-exact BMP)", "value": main_rates["value"], "unit": "MPix/s",
             "value_mode": (f"{nfl} batches in flight (each resident batch on its own HIP stream; every step drained and checked before its batch is "
-                           "decoded again); one_batch_in_flight = the same steps strictly serialised") if nfl > 1 else "one batch at a time",
+                           "decoded again; planned with PJD_PLAN_THROUGHPUT); one_batch_in_flight = the same steps strictly serialised on ONE "
+                           "batch planned with PJD_PLAN_LATENCY (the library's default); --plan-mode forces one plan for both") if nfl > 1 else "one batch at a time",
             "n_gpus": world, "rccl_ranks": comm["ranks"], "collective_backend": comm["backend"], "steps": args.steps, "warmup": max(args.warmup, nfl),
             "ms_per_step": main_rates["ms_per_step"], "higher_is_better": True, "scaling": "strong" if R.get("split") else "weak",
             "vs_baseline": None, "dtype": "int16/int32 (integer IDCT), u8 out", "data": "synthetic",
@@ -475,10 +498,15 @@ def main():
                        "images_per_gpu": info["n_images"], "pixels_per_gpu": pixels, "ecs_bytes_per_gpu": info["ecs_bytes"],
                        "bytes_per_pixel": main_rates["bytes_per_pixel"], "table_sets": info["n_table_sets"],
                        "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
+                       "device_bytes_per_batch": int(info["device_bytes"]), "lane_stream_capacity_bytes": int(info["coef_bytes"]),
+                       "lane_stream_bytes_used": int(info["n_steps"] * 4 * 8 // 7),
                        "exact_kernel_images": main_rates["exact_kernel_images"],
                        "hip_graph": not args.no_graph, "batches_in_flight": nfl, "host_nproc": os.cpu_count(),
+                       "plan_mode": "throughput" if info["plan_mode"] else "latency",
                        "sync": dict({k: info[k] for k in ("n_huff_workgroups", "n_huff_waves", "sync_rounds", "sync_lane_passes", "fix_rounds", "fix_lane_passes", "walks", "walk_lanes")},
                                     lane_passes_per_lane=round(2.0 + info["sync_lane_passes"] / max(1, info["n_subsequences"]), 3),
+                                    symbols=int(info["n_entries"]), write_steps=int(info["n_steps"]),
+                                    symbols_per_step=round(info["n_entries"] / max(1, info["n_steps"]), 3),
                                     note="lane_passes_per_lane = speculative pass + re-sync passes + write pass, per lane (work); a wave's "
                                          "re-sync round lasts as long as its slowest lane; walks = rounds a wave finished cooperatively "
                                          "(few lanes left), walk_lanes = lanes re-decoded that way (counted in sync_lane_passes too)")},
@@ -486,7 +514,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_issue_frac": valu_issue_frac,
                          "counters_from": prof_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(ktimes[dom], 4)},
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(ktimes[dom], 4),
+                         "plan_mode": "throughput" if R.get("info_alone", info)["plan_mode"] else "latency"},
             "kernels_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_pipeline_ms": round(R["ktotal"], 4),
             "host_ms": R["host_ms"],

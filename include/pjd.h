@@ -180,7 +180,7 @@ typedef struct pjd_batch_info {
                                           3 wave boundary did not stitch, 4 wait timed out, 5 lane output overflow,
                                           6 write pass did not reproduce the synchronised state                     */
     uint32_t huff_lds_bytes;           /* LDS of one entropy-decode workgroup: the largest table set of the batch + wave areas   */
-    uint32_t reserved_;
+    uint32_t plan_mode;                /* PJD_PLAN_* the batch was planned with                                                    */
     uint64_t walks, walk_lanes;        /* last decode: re-sync rounds that a wave finished as a cooperative walk (few lanes left: the
                                           whole wave decodes one lane's subsequence several times faster), and the lanes walked */
     uint64_t n_steps;                  /* last decode: steps of the write pass (a step emits one entry, or the two entries of a symbol
@@ -191,6 +191,14 @@ typedef struct pjd_batch_info {
 int  pjd_version(void);
 int  pjd_open(int device_ordinal, pjd_ctx **out);
 void pjd_close(pjd_ctx *ctx);
+/* How batches created on this context from now on are planned.  The entropy decoder cuts every bitstream into lanes; short lanes
+ * finish ONE batch sooner (every pass of every chain is shorter), long lanes cost less work per byte (fewer re-synchronisation
+ * passes), which is what counts when several batches are decoded at once (pjd_pipeline, a serving loop).  Measured on the default
+ * workload of bench.py: latency plan 2.24 ms for a batch alone / 116 GPix/s with four in flight, throughput plan 2.66 ms / 122.
+ * Pictures are identical either way.  Default: PJD_PLAN_LATENCY (PJD_PLAN_MODE=throughput in the environment changes it).      */
+#define PJD_PLAN_LATENCY     0
+#define PJD_PLAN_THROUGHPUT  1
+int  pjd_set_plan_mode(pjd_ctx *ctx, int mode);
 const char *pjd_last_error(pjd_ctx *ctx);   /* text of the last failure on this context       */
 const char *pjd_status_string(int status);  /* the reference's message for a PJD_ST_* value   */
 void *pjd_stream(pjd_ctx *ctx);             /* the hipStream_t all work is issued on          */

@@ -70,6 +70,7 @@ struct pjd_ctx {
     std::string err;
     bool force_sequential = false;
     uint32_t sub_bytes_override = 0;
+    int plan_mode = PJD_PLAN_LATENCY;     // pjd_set_plan_mode
     // picture groups: the chains of groups 1.. run on these, forked from / joined to `stream` (created on first use)
     std::vector<hipStream_t> group_streams;
     std::vector<hipEvent_t> join_ev;
@@ -200,8 +201,17 @@ int pjd_open(int device_ordinal, pjd_ctx **out)
     if (pg) c->pool_cap = (size_t)std::atoll(pg) << 30;
     const char *sb = std::getenv("PJD_SUB_BYTES");
     c->sub_bytes_override = sb ? (uint32_t)std::atoi(sb) : 0;
+    if (const char *pm = std::getenv("PJD_PLAN_MODE")) c->plan_mode = (pm[0] == 't' || pm[0] == '1') ? PJD_PLAN_THROUGHPUT : PJD_PLAN_LATENCY;
     { std::lock_guard<std::mutex> l(g_ctx_m); g_ctxs.push_back(c); }
     *out = c;
+    return PJD_OK;
+}
+
+int pjd_set_plan_mode(pjd_ctx *ctx, int mode)
+{
+    if (!ctx) return PJD_E_ARG;
+    if (mode != PJD_PLAN_LATENCY && mode != PJD_PLAN_THROUGHPUT) { ctx->err = "unknown plan mode"; return PJD_E_ARG; }
+    ctx->plan_mode = mode;
     return PJD_OK;
 }
 
@@ -267,7 +277,7 @@ int pjd_batch_create(pjd_ctx *ctx, const pjd_image_desc *images, int n_images, i
     *out = nullptr;
     pjd_batch *b = new pjd_batch;
     b->ctx = ctx;
-    int rc = pjd_make_plan(images, n_images, out_format, b->plan, ctx->err, ctx->sub_bytes_override);
+    int rc = pjd_make_plan(images, n_images, out_format, b->plan, ctx->err, ctx->sub_bytes_override, ctx->plan_mode);
     if (rc != PJD_OK) { delete b; return rc; }
     PjdPlan &P = b->plan;
     hipSetDevice(ctx->device);
@@ -791,6 +801,7 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
     info->exact_fallback_ms = b->exact_fallback_ms;
     info->n_entropy_errors = b->n_entropy_errors;
     info->sub_bytes = P.sub_bytes;
+    info->plan_mode = (uint32_t)P.plan_mode;
     info->n_table_sets = (uint32_t)P.tsets.size();
     info->huff_lds_bytes = (uint32_t)(P.max_lut_bytes + PJD_HUFF_WAVES * (PJD_WAVE_LDS + PJD_PHASE_LDS) + 16);
     info->n_huff_waves = P.hwaves.size();
@@ -858,7 +869,9 @@ int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pj
     if (!info) return PJD_E_ARG;
     PjdPlan P;
     std::string err;
-    int rc = pjd_make_plan(images, n_images, out_format, P, err);
+    int mode = PJD_PLAN_LATENCY;           // as pjd_open: the environment's plan mode
+    if (const char *pm = std::getenv("PJD_PLAN_MODE")) mode = (pm[0] == 't' || pm[0] == '1') ? PJD_PLAN_THROUGHPUT : PJD_PLAN_LATENCY;
+    int rc = pjd_make_plan(images, n_images, out_format, P, err, 0, mode);
     if (rc != PJD_OK) return rc;
     std::memset(info, 0, sizeof *info);
     info->n_images = (int32_t)P.images.size();
@@ -868,6 +881,7 @@ int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pj
     info->n_subsequences = P.subs.size();
     info->n_sequential = (int32_t)P.seq_images.size();
     info->sub_bytes = P.sub_bytes;
+    info->plan_mode = (uint32_t)P.plan_mode;
     info->n_table_sets = (uint32_t)P.tsets.size();
     info->huff_lds_bytes = (uint32_t)(P.max_lut_bytes + PJD_HUFF_WAVES * (PJD_WAVE_LDS + PJD_PHASE_LDS) + 16);
     info->n_huff_waves = P.hwaves.size();

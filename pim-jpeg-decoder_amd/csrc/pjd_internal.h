@@ -46,7 +46,7 @@
 // no difference with batches in flight.  PJD_WALK_MAX in the environment overrides it for every picture of a batch (0: never walk).
 #define PJD_WALK_LANES(sub_bytes)  (((sub_bytes) * 3u) >> 9)
 #define PJD_WALK_DENSE     6
-#define PJD_WALK_DENSE_MCUS 4
+#define PJD_WALK_DENSE_MCUS 6
 #define PJD_LUT_BITS       9        // first-level Huffman LUT width
 #define PJD_L2_BITS        (16 - PJD_LUT_BITS)    // a second-level table is indexed by the bits after the prefix
 #define PJD_L1_BYTES       (4 << PJD_LUT_BITS)   // one first-level table: 512 x u32 (low half: the symbol; high half: the symbol PAIR, below)
@@ -78,10 +78,12 @@
 #define PJD_GROUP          16       // slots per group = what the write pass stages between two flushes (8 dwords)
 #define PJD_GROUP_STEPS    (PJD_GROUP / 2 - 1)
 // step_bits_x256: fewest bits of stream per step the picture's table set can be made to sustain, x 256 (pjd_plan.cpp, min_step_bits_x256:
-// minimum mean cycle of the step graph) -- whole units take at most 8 * sub_bytes * 256 / step_bits_x256 steps; the two units a lane may
-// hold only in part add at most 63 steps each whatever their bits, the symbol that started before the lane and the pair the lane's end
-// breaks a few more.
-#define PJD_LANE_CAP(sub_bytes, step_bits_x256)   ((((8u * (sub_bytes) * 256u + (step_bits_x256) - 1) / (step_bits_x256) + 136u + PJD_GROUP_STEPS - 1) / PJD_GROUP_STEPS + 1u) * PJD_GROUP)
+// the minimum mean weight mu of a cycle of the step graph, 17 nodes).  A lane's steps are ONE walk in that graph: cycles (each of mean
+// >= mu) and a simple path of at most 16 edges of at least one bit each, so n steps consume at least n * mu - 16 * (mu - 1) bits: n <
+// bits / mu + 16.  The bits are the lane's own (steps START inside it) plus what its last step reads past its end (two symbols: < 27 bits,
+// at most 6 steps' worth at mu >= 4... 27 at mu = 1), and the pair the lane's end breaks is one more step: 16 + 27 + 1, rounded up.
+#define PJD_LANE_SLACK_STEPS 48u
+#define PJD_LANE_CAP(sub_bytes, step_bits_x256)   ((((8u * (sub_bytes) * 256u + (step_bits_x256) - 1) / (step_bits_x256) + PJD_LANE_SLACK_STEPS + PJD_GROUP_STEPS - 1) / PJD_GROUP_STEPS + 1u) * PJD_GROUP)
 
 // ---- coefficient entries (lane streams) --------------------------------------------------------
 // The write pass turns every decoded Huffman symbol into one 16-bit entry; a STEP word holds the one or two entries of a step:

@@ -1076,7 +1076,15 @@ __device__ __forceinline__ void finish_picture(const PjdDevBatch &B, uint32_t im
 //   * the write pass runs from registers; tables are still in LDS, the checkpoint area becomes the staging buffer.
 // hwg_base / ticket: the launch covers workgroups hwg_base .. of PjdDevBatch::hwgs and draws their indices from its own ticket
 // counter (one launch for the whole batch: 0 and B.ticket; one per picture group otherwise, pjd_internal.h).
-__global__ __launch_bounds__(PJD_HUFF_THREADS) void pjd_k_huff_lanes(PjdDevBatch B, uint32_t hwg_base, uint32_t *__restrict__ ticket)
+#ifndef PJD_HUFF_OCC
+#define PJD_HUFF_OCC 0                 // build option: waves per SIMD the register allocation must allow (0: the compiler's choice)
+#endif
+#if PJD_HUFF_OCC
+#define PJD_HUFF_OCC_ATTR __attribute__((amdgpu_waves_per_eu(PJD_HUFF_OCC, PJD_HUFF_OCC)))
+#else
+#define PJD_HUFF_OCC_ATTR
+#endif
+__global__ __launch_bounds__(PJD_HUFF_THREADS) PJD_HUFF_OCC_ATTR void pjd_k_huff_lanes(PjdDevBatch B, uint32_t hwg_base, uint32_t *__restrict__ ticket)
 {
     const uint32_t t = threadIdx.x, l = t & 63, wi = t >> 6;
     uint8_t *lds = pjd_huff_lds;

@@ -46,16 +46,17 @@ extern "C" uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_for
 // every unit is a cycle through D, so over whole units bits >= steps x (minimum mean weight of a cycle): Karp's algorithm on 17 nodes.
 // A unit may also end on any run/size symbol (it fills slot 63), which the graph allows everywhere: conservative.
 // `combos`: the (DC table, AC table, DC pairs allowed) of the components.
-struct SymBits { uint32_t len, bits; bool eob; };
+struct SymBits { uint32_t len, bits; bool eob, valid; };
 static std::vector<SymBits> table_symbols(const pjd_huff_table &t, bool ac)
 {
     std::vector<SymBits> v;
     for (int len = 1; len <= 16; len++)
         for (uint32_t q = t.offsets[len - 1]; q < t.offsets[len] && q < 162; q++) {
             const uint32_t sym = t.symbols[q];
-            if (sym == 0xFF) continue;                                       // the reference's "no symbol": decoding stops there
-            if (ac ? ((sym & 15u) > 10) : (sym > 11)) continue;              // out-of-range size: an error, decoding stops there
-            v.push_back({(uint32_t)len, (uint32_t)len + (ac ? (sym & 15u) : sym), ac && sym == 0});
+            // the reference's "no symbol" and the out-of-range sizes are errors, but the write pass decodes on to the lane's end before
+            // anyone looks: such an entry consumes its code alone and never pairs (lut_entry, pjd_k_huffman.hip)
+            const bool valid = sym != 0xFF && (ac ? (sym & 15u) <= 10 : sym <= 11);
+            v.push_back({(uint32_t)len, (uint32_t)len + (valid ? (ac ? (sym & 15u) : sym) : 0u), valid && ac && sym == 0, valid});
         }
     return v;
 }
@@ -71,20 +72,20 @@ static uint32_t min_step_bits_x256(const std::vector<std::pair<const pjd_huff_ta
     for (size_t c = 0; c < combos.size(); c++) {
         const std::vector<SymBits> dc = table_symbols(*combos[c].first, false), ac = table_symbols(*combos[c].second, true);
         for (const SymBits &x : dc) {
-            edge(0, dc_pairs[c] ? need(x.bits) : 1, x.bits);
-            if (dc_pairs[c] && x.bits <= 8)
+            edge(0, (dc_pairs[c] && x.valid) ? need(x.bits) : 1, x.bits);
+            if (dc_pairs[c] && x.valid && x.bits <= 8)
                 for (const SymBits &y : ac)
-                    if (x.bits + y.len <= 9) { edge(0, y.eob ? 0 : 1, x.bits + y.bits); edge(0, 0, x.bits + y.bits); }
+                    if (y.valid && x.bits + y.len <= 9) { edge(0, y.eob ? 0 : 1, x.bits + y.bits); edge(0, 0, x.bits + y.bits); }
         }
         for (int L = 1; L <= 16; L++)
             for (const SymBits &y : ac) {
                 if ((int)y.len < L) continue;
                 if (y.eob) { edge(L, 0, y.bits); continue; }
                 edge(L, 0, y.bits);                                          // fills slot 63: the unit ends
-                edge(L, need(y.bits), y.bits);                               // stays single: the next code is long
-                if (y.bits <= 8)
+                edge(L, y.valid ? need(y.bits) : 1, y.bits);                 // stays single: the next code is long
+                if (y.valid && y.bits <= 8)
                     for (const SymBits &z : ac)
-                        if (y.bits + z.len <= 9) { edge(L, z.eob ? 0 : 1, y.bits + z.bits); edge(L, 0, y.bits + z.bits); }
+                        if (z.valid && y.bits + z.len <= 9) { edge(L, z.eob ? 0 : 1, y.bits + z.bits); edge(L, 0, y.bits + z.bits); }
             }
     }
     // Karp: minimum mean cycle.  dist[k][v] = lightest walk of exactly k edges from anywhere to v
@@ -107,23 +108,30 @@ static uint32_t min_step_bits_x256(const std::vector<std::pair<const pjd_huff_ta
 }
 
 int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &P, std::string &err,
-                  uint32_t sub_bytes_override)
+                  uint32_t sub_bytes_override, int plan_mode)
 {
     if (n < 0 || (n > 0 && !images)) { err = "null image array"; return PJD_E_ARG; }
     if (out_format != PJD_OUT_RGB8 && out_format != PJD_OUT_BMP) { err = "unknown output format"; return PJD_E_ARG; }
     P = PjdPlan();
     P.out_format = out_format;
+    P.plan_mode = plan_mode == PJD_PLAN_THROUGHPUT ? PJD_PLAN_THROUGHPUT : PJD_PLAN_LATENCY;
     P.images.resize(n);
     P.host.resize(n);
     P.qtab.assign((size_t)n * 3 * 64, 0);
 
     // Subsequence size.  A decoder started at a wrong position falls into step with the true one only when bit position,
     // zigzag slot AND the phase inside the MCU all agree; measured, that takes about two MCUs' worth of stream on average
-    // with a long tail (4:2:0: ~160 B at 80 B per MCU, several times that for dense high-quality streams).  A lane should
-    // be several times that long -- 8 MCUs' worth here (measured on the default batch: 3.5 / 4.5 / 5.5 / 6.5 / 8 / 10 MCUs ->
-    // 65.0 / 64.0 / 64.7 / 65.8 / 68.8 / 68.3 GPix/s in flight, 6.55 / 6.71 / 6.63 / 6.72 / 6.25 / 6.24 ms alone; subsequences
-    // of up to 2048 bytes were not better than the 1024-byte cap) -- or most lanes need more than one re-sync round; but a
-    // small batch needs enough lanes to fill 256 CUs.
+    // with a long tail (4:2:0: ~160 B at 80 B per MCU, several times that for dense high-quality streams).  Longer lanes mean
+    // fewer re-sync passes per byte (less work: what counts with batches in flight), shorter lanes mean shorter passes, rounds and
+    // write passes on every chain (what counts for one batch alone).  Round 4, after the second landing pad and the symbol pairs
+    // (profiles/r04_experiments.md #18), default batch, stream of 8 / 4.5 / 4 / 3.5 / 3 / 2.5 MCUs per lane (capped at 1024 B):
+    // entropy decoder alone 2.18 / 2.45 / 2.05 / 1.87 / 2.04 / 2.19 ms, one batch 2.56 / 2.83 / 2.33 / 2.23 / 2.29 / 2.45 ms, four
+    // batches in flight 116.5 / 117.1 / 114.9 / 114.3 / 111.3 / 107.5 GPix/s on the same box (8 MCUs on another: 118.6):
+    // and 6 MCUs with the walker threshold of 8 (6 lanes): one batch 2.66, in flight 122.2 against 116.0 for 3.5 MCUs on one box.
+    // Neither serves both, so the caller says what it runs (pjd_set_plan_mode): 3.5 MCUs' worth for a batch that is decoded alone
+    // (PJD_PLAN_LATENCY, the default: 16 % off the batch's time), 6 MCUs' worth for batches kept in flight (PJD_PLAN_THROUGHPUT:
+    // 5 % more pictures per second).  (Round 2, before either change: 8 MCUs was best for both.)  A small batch needs enough
+    // lanes to fill 256 CUs.
     {
         uint64_t total = 0, mcus = 0;
         for (int i = 0; i < n; i++) {
@@ -132,7 +140,8 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
             mcus += (uint64_t)((images[i].width + 8 * hs - 1) / (8 * hs)) * ((images[i].height + 8 * vs - 1) / (8 * vs));
         }
         const uint32_t by_total = total >= (64u << 20) ? (uint32_t)PJD_SUB_BYTES_MAX : (total >= (24u << 20) ? 512u : (total >= (2u << 20) ? 256u : 128u));
-        static const uint64_t mcus_x2 = [] { const char *e = std::getenv("PJD_SUB_MCUS_X2"); const int v = e ? std::atoi(e) : 0; return (uint64_t)(v > 0 ? v : 16); }();   // experiments: subsequence = this many half-MCUs of stream
+        static const uint64_t mcus_x2_env = [] { const char *e = std::getenv("PJD_SUB_MCUS_X2"); const int v = e ? std::atoi(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();   // experiments: subsequence = this many half-MCUs of stream
+        const uint64_t mcus_x2 = mcus_x2_env ? mcus_x2_env : (P.plan_mode == PJD_PLAN_THROUGHPUT ? 12 : 7);
         uint64_t by_density = mcus ? (total * mcus_x2 / 2 / mcus + 63) / 64 * 64 : 512;
         if (by_density < PJD_SUB_BYTES_MIN) by_density = PJD_SUB_BYTES_MIN;
         if (by_density > PJD_SUB_BYTES_MAX) by_density = PJD_SUB_BYTES_MAX;

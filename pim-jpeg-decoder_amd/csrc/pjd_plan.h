@@ -51,9 +51,11 @@ struct PjdPlan {
     uint64_t lut_buf_bytes = 0;            // decode-table blobs of all table sets the parallel path uses
     uint32_t max_lut_bytes = 0;            // largest blob (dynamic LDS of the Huffman kernel)
     uint64_t pixels = 0, ecs_bytes = 0, out_bytes = 0;
+    int plan_mode = 0;                     // PJD_PLAN_*
 };
 
 // Returns PJD_OK or PJD_E_ARG (with a message in `err`).
 // sub_bytes_override: 0 = choose from the batch size, else a multiple of 64 in [PJD_SUB_BYTES_MIN, PJD_SUB_BYTES_MAX].
+// plan_mode: PJD_PLAN_LATENCY / PJD_PLAN_THROUGHPUT (include/pjd.h): how much stream a lane takes.
 int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &plan, std::string &err,
-                  uint32_t sub_bytes_override = 0);
+                  uint32_t sub_bytes_override = 0, int plan_mode = 0);

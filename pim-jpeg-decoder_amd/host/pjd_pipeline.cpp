@@ -327,6 +327,8 @@ struct Pipe {
                 for (int k = 0; k < o.slots; k++) {
                     SlotRes s = take_slot(dev);
                     if (!s.ctx) { park_slot(s); break; }
+                    // several slots per device decode at once: plan for pictures per second; one slot decodes its batches alone
+                    pjd_set_plan_mode(s.ctx, o.slots > 1 ? PJD_PLAN_THROUGHPUT : PJD_PLAN_LATENCY);
                     r.push_back(s);
                 }
                 if (!r.empty()) { live.push_back(dev); entry_of.push_back((int)di); res.push_back(std::move(r)); }

@@ -16,6 +16,7 @@ LIBHOST = os.path.join(LIB_DIR, "libpjdhost.so")
 LIBPIPE = os.path.join(LIB_DIR, "libpjdpipe.so")
 
 OUT_RGB8, OUT_BMP = 0, 1
+PLAN_LATENCY, PLAN_THROUGHPUT = 0, 1      # pjd_set_plan_mode
 F_STANDARD_RESTART, F_FORCE_SEQUENTIAL, F_STANDARD_ZIGZAG, F_PROGRESSIVE = 1, 2, 4, 8
 SCAN_PROGRESSIVE = 1
 MAX_KERNELS = 16
@@ -67,7 +68,7 @@ class BatchInfo(C.Structure):
                 ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64),
                 ("sub_bytes", C.c_uint32), ("n_table_sets", C.c_uint32), ("n_huff_waves", C.c_uint64),
                 ("n_entries", C.c_uint64), ("exact_fallback_ms", C.c_float), ("n_entropy_errors", C.c_uint32),
-                ("flag_waves", C.c_uint64 * 8), ("huff_lds_bytes", C.c_uint32), ("reserved_", C.c_uint32), ("walks", C.c_uint64), ("walk_lanes", C.c_uint64), ("n_steps", C.c_uint64)]
+                ("flag_waves", C.c_uint64 * 8), ("huff_lds_bytes", C.c_uint32), ("plan_mode", C.c_uint32), ("walks", C.c_uint64), ("walk_lanes", C.c_uint64), ("n_steps", C.c_uint64)]
 
 
 SPLIT_MAX_DEVICES = 16
@@ -134,6 +135,8 @@ def dev_lib():
         L.pjd_open.restype = i32
         L.pjd_open.argtypes = [i32, C.POINTER(vp)]
         L.pjd_close.argtypes = [vp]
+        L.pjd_set_plan_mode.restype = i32
+        L.pjd_set_plan_mode.argtypes = [vp, i32]
         L.pjd_last_error.restype = C.c_char_p
         L.pjd_last_error.argtypes = [vp]
         L.pjd_status_string.restype = C.c_char_p
@@ -244,7 +247,7 @@ def rgb_to_bmp(rgb: np.ndarray) -> bytes:
 class Context:
     """One GPU (replaces DpuSet::allocate + load of the reference)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, plan_mode: int = None):
         L = dev_lib()
         h = C.c_void_p()
         rc = L.pjd_open(device, C.byref(h))
@@ -252,6 +255,13 @@ class Context:
             raise PjdError(f"pjd_open({device}) failed with {rc}: no usable gfx950 device")
         self._h = h
         self.L = L
+        if plan_mode is not None:
+            self.set_plan_mode(plan_mode)
+
+    def set_plan_mode(self, mode: int):
+        """PLAN_LATENCY (a batch decoded alone finishes sooner) or PLAN_THROUGHPUT (batches kept in flight: more pictures per second);
+        applies to batches created afterwards (include/pjd.h, pjd_set_plan_mode)."""
+        self._check(self.L.pjd_set_plan_mode(self._h, int(mode)), "pjd_set_plan_mode")
 
     def close(self):
         if self._h:

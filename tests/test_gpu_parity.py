@@ -673,7 +673,7 @@ def test_two_batches_in_flight_on_two_contexts(port):
 
 
 # ---- stage-level parity: the entropy decoder alone, against the reference's own decode_Huffman_data -----------------------------
-@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "fast-throughput-plan"])
 def test_coefficients_match_reference_hashes(ctx, mode):
     """SURVEY section 4 'stage-level dumps: coef after Huffman'.  manifest.json's coef_sha256 is the sha256 of the reference's
     MCU_buffer after ITS decode_Huffman_data (src/jpeg_scanner.cpp:707-756, run by oracle/_ref when the fixtures were made).
@@ -683,16 +683,18 @@ def test_coefficients_match_reference_hashes(ctx, mode):
     import pjd_amd
     flags = pjd_amd.F_FORCE_SEQUENTIAL if mode == "exact" else 0
     scanned = [_desc(n, flags) for n in VALID]
+    ctx.set_plan_mode(pjd_amd.PLAN_THROUGHPUT if mode == "fast-throughput-plan" else pjd_amd.PLAN_LATENCY)      # how long the lanes are (pjd.h)
     with ctx.batch([s.desc for s in scanned], pjd_amd.OUT_RGB8) as b:
         b.upload(); b.decode(); b.sync()
         info = b.info()
+        assert info["plan_mode"] == (pjd_amd.PLAN_THROUGHPUT if mode == "fast-throughput-plan" else pjd_amd.PLAN_LATENCY)
         bad = []
         for i, name in enumerate(VALID):
             got = hashlib.sha256(b.coefficients(i).tobytes()).hexdigest()
             if got != MANIFEST[name]["coef_sha256"]:
                 bad.append(name)
         assert not bad, bad
-    if mode == "fast":      # most of them really came out of the lane streams
+    if mode != "exact":     # most of them really came out of the lane streams
         assert info["n_sequential"] + info["n_fallback"] < len(VALID) // 4
 
 
@@ -1199,6 +1201,51 @@ def test_idle_device_forms_equal_the_single_chain(ctx, port):
         assert results[0][0][i] == w["bmp"], i
         n_err += w["huff_rc"] != 0
     assert n_err >= 1 and info["n_fallback"] == 0
+
+
+def test_plan_modes_give_the_same_pictures(port):
+    """pjd_set_plan_mode changes how much stream a lane of the entropy decoder takes (latency plan: 3.5 MCUs' worth, throughput
+    plan: 6; only batches of 64 MB and more have lanes that long) and nothing else: pictures and statuses of a mixed batch of 640
+    pictures -- dense and flat streams, restart intervals, every sampling mode, two damaged pictures -- are the same under both
+    plans, every 16th picture and the special ones equal the oracle, and the plans really differ."""
+    import pjd_amd
+    synth = _synth()
+    jpegs = synth.cfg3_imagenet_like(600, seed=31, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True)
+    jpegs += synth.cfg3_imagenet_like(35, seed=32)
+    jpegs += [synth.make(1333, 900, 7, 97, synth.SUB_420, 0, synth.DENSE_DETAIL, True), synth.make(640, 480, 8, 95, synth.SUB_444, 5),
+              synth.make(801, 377, 9, 50, synth.SUB_422, 0), synth.make(264, 800, 10, 90, synth.SUB_440, 0), synth.make(499, 399, 11, 75, synth.SUB_GREY, 4)]
+    for k in (3, 50):
+        ba = bytearray(jpegs[k])
+        body = bytes(ba).rfind(b"\xff\xda") + 14
+        pos = body + (len(ba) - body) // 3
+        while 0xFF in ba[pos - 1:pos + 5]:
+            pos += 1
+        ba[pos:pos + 4] = b"\xff\x00\xff\x00"
+        jpegs[k] = bytes(ba)
+    scanned = [pjd_amd.Scanned(j) for j in jpegs]
+    assert all(s.valid for s in scanned)
+    sample = sorted(set(range(0, len(jpegs), 16)) | {3, 50} | set(range(len(jpegs) - 5, len(jpegs))))
+    want = {i: port.decode(jpegs[i]) for i in sample}
+    lanes, res = {}, {}
+    for mode in (pjd_amd.PLAN_LATENCY, pjd_amd.PLAN_THROUGHPUT):
+        c = pjd_amd.Context(0, plan_mode=mode)
+        try:
+            with c.batch([s.desc for s in scanned], pjd_amd.OUT_BMP) as b:
+                b.upload(); b.decode(); b.sync()
+                outs, st = b.download()
+                info = b.info()
+                lanes[mode] = info["n_subsequences"]
+                assert info["plan_mode"] == mode and info["n_fallback"] == 0 and info["flag_waves"][5] == 0
+                for i, w in want.items():
+                    assert st[i] == w["huff_rc"], (mode, i)
+                    assert outs[i].tobytes() == w["bmp"], (mode, i)
+                for i in (3, 48, 50, len(jpegs) - 5, len(jpegs) - 3):
+                    assert np.array_equal(b.coefficients(i), want[i]["coef"]), (mode, i)
+                res[mode] = ([hashlib.sha256(o.tobytes()).digest() for o in outs], list(st))
+        finally:
+            c.close()
+    assert res[pjd_amd.PLAN_LATENCY] == res[pjd_amd.PLAN_THROUGHPUT]
+    assert lanes[pjd_amd.PLAN_LATENCY] > lanes[pjd_amd.PLAN_THROUGHPUT] * 5 // 4
 
 
 def test_pull_form_of_the_back_end_is_bit_exact():
