@@ -484,7 +484,7 @@ int enqueue_decode(pjd_batch *b, pjd_timings *timings, bool use_groups)
                      b->dev.dbg ? (uint32_t)(P.hwaves.size() * 32) : 0u);
     kt.mark("reset");
     // What a decode looks like on an otherwise idle device (use_groups), for a batch of many small pictures (the planner made groups):
-    //   "groups" (default) two chains of launches, dense and light pictures, on two streams
+    //   "groups" (default) three chains of launches (pictures by density) on three streams
     //   "pull"   the back end runs BESIDE the entropy decoder and takes pictures as their last wave completes them (pjd_internal.h).
     //            Bit-exact and complete (the GPU suite passes in this form), but SLOWER: the back end's waves share SIMDs with the
     //            entropy decoder's chains and stretch them -- 3.4-3.5 ms per batch against 2.6-2.7 for "groups" and 2.9 for "chain"

@@ -547,13 +547,15 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
         P.hwgs.swap(ordered);
         // Picture groups (pjd_internal.h): cut the start order into runs of about equal numbers of waves, densest pictures first.
         // Only for batches of many small pictures: the group's DC predictors are scanned by one workgroup per picture.
-        // Two groups by default, cut at 30 % of the waves: the first group -- the densest pictures, whose entropy decode ends last -- is
-        // the smaller one, because its back end is what is left to do when the last chain of re-sync rounds has finished.  Measured for
-        // one batch alone (profiles/r04_experiments.md): no groups 2.89 ms, cut at 30 % 2.60, thirds 2.59-2.61, 20/55 % 2.66,
-        // 12/35/65 % 2.67; six groups 4.1 (more streams than the runtime's four hardware queues: chains queue behind each other).
+        // The first group -- the densest pictures, whose entropy decode ends last -- is the smallest: every group's entropy decode lasts
+        // about as long as its longest chain of re-sync rounds whatever its share of the work, and what a group adds behind that is its
+        // own back end.  Measured for one batch alone (profiles/r04_experiments.md): round-3 lanes (8 MCUs' worth): no groups 2.89 ms,
+        // two groups cut at 30 % 2.60, thirds 2.59-2.61, 20/55 % 2.66, 12/35/65 % 2.67, six groups 4.1 (more streams than the runtime's
+        // four hardware queues: chains queue behind each other); latency-plan lanes (3.5 MCUs' worth): no groups 2.50, 30 % 2.23,
+        // 40 / 50 % 2.21 / 2.20, 30/65 % 2.11, 35/70 2.12, 25/60 2.18, 25/50/75 2.12, 30/55/80 2.10: three groups, cut at 30 and 65 %.
         // PJD_GROUPS / PJD_GROUP_CUTS ("20,55": percent of the waves) for experiments.
-        uint32_t want = 2;
-        std::vector<uint32_t> cuts_pct = {30};
+        uint32_t want = 3;
+        std::vector<uint32_t> cuts_pct = {30, 65};
         if (const char *e = std::getenv("PJD_GROUPS")) { const int v = std::atoi(e); want = (uint32_t)(v < 1 ? 1 : (v > PJD_MAX_GROUPS ? PJD_MAX_GROUPS : v)); cuts_pct.clear(); }
         if (const char *e = std::getenv("PJD_GROUP_CUTS")) {
             cuts_pct.clear();

@@ -1147,8 +1147,8 @@ def test_error_in_a_unit_that_runs_on_into_the_next_lane(port, monkeypatch):
 
 
 def test_idle_device_forms_equal_the_single_chain(ctx, port):
-    """A batch of many small pictures decoded on an otherwise idle device is issued as two chains of launches (picture groups:
-    dense and light pictures on two streams); the same batch decoded while another decode of the process is on the device keeps
+    """A batch of many small pictures decoded on an otherwise idle device is issued as several chains of launches (picture groups:
+    pictures by density, one stream per group); the same batch decoded while another decode of the process is on the device keeps
     to one chain.  Same pictures, statuses and coefficients either way, also replayed as captured graphs, also with damaged
     pictures in the batch; and both equal the oracle."""
     import pjd_amd

@@ -15,6 +15,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq1" -- $CMD > "$OUT/sq1.log" 2>&1; echo "sq1 rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$OUT/sq2" -- $CMD > "$OUT/sq2.log" 2>&1; echo "sq2 rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_LDS_IDX_ACTIVE SQ_INSTS_SENDMSG --kernel-trace --output-format csv -d "$OUT/sq3" -- $CMD > "$OUT/sq3.log" 2>&1; echo "sq3 rc=$?"
+# the same counters for the throughput plan (longer lanes: what the batches kept in flight are planned with)
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq1_thr" -- $CMD --plan-mode throughput > "$OUT/sq1_thr.log" 2>&1; echo "sq1_thr rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_thr" -- $CMD --plan-mode throughput > "$OUT/stats_thr.log" 2>&1; echo "stats_thr rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1; echo "write rc=$?"
 # kernel trace of the default mode (four batches in flight): which kernels overlap (tools/inflight_overlap.py)
