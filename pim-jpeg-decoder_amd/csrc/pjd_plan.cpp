@@ -47,60 +47,91 @@ extern "C" uint64_t pjd_output_size(uint32_t width, uint32_t height, int out_for
 // A unit may also end on any run/size symbol (it fills slot 63), which the graph allows everywhere: conservative.
 // `combos`: the (DC table, AC table, DC pairs allowed) of the components.
 struct SymBits { uint32_t len, bits; bool eob, valid; };
-static std::vector<SymBits> table_symbols(const pjd_huff_table &t, bool ac)
+static int table_symbols(const pjd_huff_table &t, bool ac, SymBits *v)
 {
-    std::vector<SymBits> v;
+    int n = 0;
     for (int len = 1; len <= 16; len++)
         for (uint32_t q = t.offsets[len - 1]; q < t.offsets[len] && q < 162; q++) {
             const uint32_t sym = t.symbols[q];
             // the reference's "no symbol" and the out-of-range sizes are errors, but the write pass decodes on to the lane's end before
             // anyone looks: such an entry consumes its code alone and never pairs (lut_entry, pjd_k_huffman.hip)
             const bool valid = sym != 0xFF && (ac ? (sym & 15u) <= 10 : sym <= 11);
-            v.push_back({(uint32_t)len, (uint32_t)len + (valid ? (ac ? (sym & 15u) : sym) : 0u), valid && ac && sym == 0, valid});
+            v[n++] = {(uint32_t)len, (uint32_t)len + (valid ? (ac ? (sym & 15u) : sym) : 0u), valid && ac && sym == 0, valid};
         }
-    return v;
+    return n;
 }
 static uint32_t min_step_bits_x256(const std::vector<std::pair<const pjd_huff_table *, const pjd_huff_table *>> &combos, const std::vector<char> &dc_pairs)
 {
-    const int V = 17;                                    // 0: D, L = 1..16: A_L
+    enum { V = 17 };                                     // 0: D, L = 1..16: A_L
     const uint32_t INF = 1u << 30;
-    std::vector<uint32_t> w((size_t)V * V, INF);
-    auto edge = [&](int u, int v, uint32_t bits) { if (bits < w[(size_t)u * V + v]) w[(size_t)u * V + v] = bits; };
+    uint32_t w[V][V];
+    for (int u = 0; u < V; u++) for (int v = 0; v < V; v++) w[u][v] = INF;
+    auto lower = [](uint32_t &dst, uint32_t bits) { if (bits < dst) dst = bits; };
     // the code after a symbol that stayed single is at least this long (a pair broken for another reason -- the lane ends -- happens once
     // per lane: PJD_LANE_CAP's slack)
     auto need = [](uint32_t first_bits) { return first_bits >= 9 ? 1 : (int)(10 - first_bits); };
     for (size_t c = 0; c < combos.size(); c++) {
-        const std::vector<SymBits> dc = table_symbols(*combos[c].first, false), ac = table_symbols(*combos[c].second, true);
-        for (const SymBits &x : dc) {
-            edge(0, (dc_pairs[c] && x.valid) ? need(x.bits) : 1, x.bits);
-            if (dc_pairs[c] && x.valid && x.bits <= 8)
-                for (const SymBits &y : ac)
-                    if (y.valid && x.bits + y.len <= 9) { edge(0, y.eob ? 0 : 1, x.bits + y.bits); edge(0, 0, x.bits + y.bits); }
+        bool seen = false;                               // Cb and Cr mostly share their tables: once is enough
+        for (size_t k = 0; k < c; k++) seen = seen || (combos[k] == combos[c] && dc_pairs[k] == dc_pairs[c]);
+        if (seen) continue;
+        SymBits dc[162], ac[162];
+        const int ndc = table_symbols(*combos[c].first, false, dc), nac = table_symbols(*combos[c].second, true, ac);
+        // the cheapest second symbol of a pair whose code fits r bits: any (the unit may end there: an EOB, or slot 63 filled) / one
+        // that leaves the unit open
+        uint32_t any2[10], open2[10];
+        for (int r = 0; r < 10; r++) any2[r] = open2[r] = INF;
+        for (int i = 0; i < nac; i++)
+            if (ac[i].valid)
+                for (uint32_t r = ac[i].len; r < 10; r++) { lower(any2[r], ac[i].bits); if (!ac[i].eob) lower(open2[r], ac[i].bits); }
+        for (int i = 0; i < ndc; i++) {
+            const SymBits &x = dc[i];
+            const bool pairs = dc_pairs[c] && x.valid;
+            lower(w[0][pairs ? need(x.bits) : 1], x.bits);
+            if (pairs && x.bits <= 8) {
+                const uint32_t r = 9 - x.bits;
+                if (open2[r] < INF) lower(w[0][1], x.bits + open2[r]);
+                if (any2[r] < INF) lower(w[0][0], x.bits + any2[r]);
+            }
         }
-        for (int L = 1; L <= 16; L++)
-            for (const SymBits &y : ac) {
-                if ((int)y.len < L) continue;
-                if (y.eob) { edge(L, 0, y.bits); continue; }
-                edge(L, 0, y.bits);                                          // fills slot 63: the unit ends
-                edge(L, y.valid ? need(y.bits) : 1, y.bits);                 // stays single: the next code is long
-                if (y.valid && y.bits <= 8)
-                    for (const SymBits &z : ac)
-                        if (z.valid && y.bits + z.len <= 9) { edge(L, z.eob ? 0 : 1, y.bits + z.bits); edge(L, 0, y.bits + z.bits); }
+        // an AC symbol with a code of `len` bits is an edge out of every A_L with L <= len: collect by length, then take suffix minima
+        uint32_t by_len[V][V];
+        for (int u = 0; u < V; u++) for (int v = 0; v < V; v++) by_len[u][v] = INF;
+        for (int i = 0; i < nac; i++) {
+            const SymBits &y = ac[i];
+            uint32_t *e = by_len[y.len];
+            lower(e[0], y.bits);                                             // EOB, or slot 63 filled: the unit ends
+            if (y.eob) continue;
+            lower(e[y.valid ? need(y.bits) : 1], y.bits);                    // stays single: the next code is long
+            if (y.valid && y.bits <= 8) {
+                const uint32_t r = 9 - y.bits;
+                if (open2[r] < INF) lower(e[1], y.bits + open2[r]);
+                if (any2[r] < INF) lower(e[0], y.bits + any2[r]);
+            }
+        }
+        for (int L = 16; L >= 1; L--)
+            for (int v = 0; v < V; v++) {
+                if (L < 16) lower(by_len[L][v], by_len[L + 1][v]);
+                lower(w[L][v], by_len[L][v]);
             }
     }
     // Karp: minimum mean cycle.  dist[k][v] = lightest walk of exactly k edges from anywhere to v
-    std::vector<std::vector<uint64_t>> dist(V + 1, std::vector<uint64_t>(V, (uint64_t)1 << 40));
+    const uint64_t FAR = (uint64_t)1 << 40;
+    uint64_t dist[V + 1][V];
     for (int v = 0; v < V; v++) dist[0][v] = 0;
-    for (int k = 1; k <= V; k++)
-        for (int u = 0; u < V; u++)
+    for (int k = 1; k <= V; k++) {
+        for (int v = 0; v < V; v++) dist[k][v] = FAR;
+        for (int u = 0; u < V; u++) {
+            if (dist[k - 1][u] >= FAR) continue;
             for (int v = 0; v < V; v++)
-                if (w[(size_t)u * V + v] < INF && dist[k - 1][u] + w[(size_t)u * V + v] < dist[k][v]) dist[k][v] = dist[k - 1][u] + w[(size_t)u * V + v];
+                if (w[u][v] < INF && dist[k - 1][u] + w[u][v] < dist[k][v]) dist[k][v] = dist[k - 1][u] + w[u][v];
+        }
+    }
     double best = 1e9;
     for (int v = 0; v < V; v++) {
-        if (dist[V][v] >= ((uint64_t)1 << 40)) continue;
+        if (dist[V][v] >= FAR) continue;
         double worst = -1e9;
         for (int k = 0; k < V; k++)
-            if (dist[k][v] < ((uint64_t)1 << 40)) worst = std::max(worst, (double)((int64_t)dist[V][v] - (int64_t)dist[k][v]) / (double)(V - k));
+            if (dist[k][v] < FAR) worst = std::max(worst, (double)((int64_t)dist[V][v] - (int64_t)dist[k][v]) / (double)(V - k));
         best = std::min(best, worst);
     }
     if (best > 64.0 || best < 1.0) best = best < 1.0 ? 1.0 : 64.0;
