@@ -21,7 +21,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1; echo "write rc=$?"
 # kernel trace of the default mode (four batches in flight): which kernels overlap (tools/inflight_overlap.py)
-CMD3="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 4 --e2e-batches 0 --no-cpu-baseline --no-cli --steps 16"
+CMD3="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 4 --plan-mode throughput --e2e-batches 0 --no-cpu-baseline --no-cli --steps 16"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/inflight" -- $CMD3 > "$OUT/inflight.log" 2>&1; echo "inflight rc=$?"
 # one batch alone with the picture groups on (the library's choice on an idle device): which kernels overlap
 unset PJD_GROUPS
