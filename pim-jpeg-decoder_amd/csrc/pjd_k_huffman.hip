@@ -736,6 +736,7 @@ struct Careful {
     uint32_t mark_next, mark_D, ru, lane_q;
     // out
     uint32_t n;            // slots written (heads included; two per step word)
+    uint32_t ovf;          // a step word did not fit the lane's region (never, by the planner's bound: the picture goes to the exact kernel)
     uint32_t cls;          // PJD_ST_* of the error, 0: none found
     uint32_t p_err, D_err, in_dc;
     uint32_t dcA, dcB;
@@ -750,7 +751,7 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
     w.init(wave_words, col, p);
     uint4 cur = lds_u32x4(P.self(P.dus1 - c));      // .x tables, .y own record, .z / .w DC-sum selectors of the current unit
     int zb = 63 - (int)z;
-    R.n = 0; R.cls = 0; R.p_err = 0; R.D_err = 0; R.in_dc = 0; R.dcA = 0; R.dcB = 0;
+    R.n = 0; R.ovf = 0; R.cls = 0; R.p_err = 0; R.D_err = 0; R.in_dc = 0; R.dcA = 0; R.dcB = 0;
     const bool at_end = eof_rel != 0xffffffffu;
     // A symbol that leaves its unit open waits one turn in its step word: the symbol after it (an AC symbol of the same unit) joins it
     // as entry B.  Never more steps than the fast pass takes for the same symbols (its pairs are a subset of these), which is what the
@@ -794,6 +795,7 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
             if (!is_dc) {
                 if (open) region32[open_at] = open_ent | (PJD_ENT_EOB << 16);
                 else if (R.n + 2 <= cap) { region32[R.n >> 1] = PJD_ENT_EOB | (PJD_ENT_NONE << 16); R.n += 2; }
+                else R.ovf = 1;
             }
             break;
         }
@@ -808,7 +810,7 @@ __device__ __forceinline__ void careful_span(const PhaseCtx &P, pjd_gptr wave_wo
             region32[R.n >> 1] = ent | (PJD_ENT_NONE << 16);
             open = !done; open_at = R.n >> 1; open_ent = ent;
             R.n += 2;
-        }
+        } else R.ovf = 1;
         const uint32_t dv = is_dc ? ((uint32_t)val & 0xffffu) : 0u, dvv = dv | (dv << 16);
         R.dcA = pk_add16(R.dcA, dvv & cur.z);
         R.dcB = pk_add16(R.dcB, dvv & cur.w);
@@ -1343,7 +1345,8 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) PJD_HUFF_OCC_ATTR void pjd_k_huff
                 li.n_ent = R.n;
                 npair = 0;
                 li.dc_sum[0] = (uint16_t)R.dcA; li.dc_sum[1] = (uint16_t)(R.dcA >> 16); li.dc_sum[2] = (uint16_t)R.dcB;
-                if (R.cls) {
+                if (R.ovf) flag |= 1u << PJD_FLAG_OVERFLOW;
+                else if (R.cls) {
                     const unsigned long long key = ((unsigned long long)(g.base_bit + R.p_err) << 32) | ((unsigned long long)R.D_err << 4) | (R.cls << 1) | R.in_dc;
                     atomicMin(&B.imstate[hw.image].err_key, key);
                     settled = true;
