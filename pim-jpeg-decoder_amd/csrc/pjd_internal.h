@@ -67,8 +67,8 @@
 #define PJD_COEF_SENTINEL  (-32768) // "slot 52 was visited with an explicit 0" (zigzag quirk)
 
 // Bitstream words of one wave, transposed: row k holds big-endian word k of each of its 64 lanes, counted from
-// the lane's own first byte.  A lane reads at most 27 bits past its subsequence and keeps two words in flight.
-#define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 4)
+// the lane's own first byte.  A lane reads at most 31 bits past its subsequence, holds three words and keeps two more in flight.
+#define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 8)
 // Slots (2 bytes each) of a lane's region.  The write pass emits one 32-bit STEP word per decode step -- one symbol, or the PAIR of
 // symbols one table lookup yields (below).  How many steps a lane of `sub_bytes` bytes can take follows from the PICTURE's table set:
 // the planner computes the fewest bits per step any stream can sustain with it (Annex-K tables: 4 -- a flat unit, DC + EOB, is one

@@ -237,6 +237,62 @@ struct BitWin {
     }
 };
 
+// The window of the passes that run with all 64 lanes (sync_span, write_span).  With BitWin a lane fetches its next word when it runs
+// out of bits -- every ~4 steps per lane, so in EVERY step of the wave some lane does, and the wait before the fetched register is
+// reused (s_waitcnt vmcnt(0): the counter is the wave's, in issue order) is a wait for the load of the step before: a step lasted as
+// long as a load from the memory-side cache (~545 cycles; ~900 from HBM) instead of its ~300 cycles of table lookups and selects
+// (profiles/r04_experiments.md #25: 54 % of the kernel's wave-cycles were such waits).  Here a lane holds 96 bits (w0..w2), two more
+// words are in flight (n0, n1), and the window is SERVICED once every TWO steps, by all lanes together: shift by the 0..2 words the two
+// steps used up, fetch the two words behind the new window -- the same ones again if the lane did not move (a load into a register
+// that already holds the value).  What a service waits for was requested two steps earlier.
+//   r = bits of w0 not yet consumed (0..31 after a service; down to -62 before the next: a step takes at most 31 bits)
+struct BitWin2 {
+    pjd_gptr wb;
+    uint32_t w0, w1, w2, n0, n1;
+    uint32_t off;         // byte offset (from wb) of n0's word
+    int r;
+    __device__ __forceinline__ uint32_t word(uint32_t byte_off) const
+    {
+        return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(wb + byte_off);
+    }
+    __device__ __forceinline__ void init(pjd_gptr wave_words, uint32_t col, uint32_t p)
+    {
+        wb = wave_words;
+        const int kk = (int)((p + 31) >> 5) - 1;          // word holding bit p-1 (or -1 at p == 0)
+        const uint32_t o = (uint32_t)(kk + 1) * PJD_WORD_STRIDE + col;
+        w0 = kk >= 0 ? word(o - PJD_WORD_STRIDE) : 0u;
+        w1 = word(o);
+        w2 = word(o + PJD_WORD_STRIDE);
+        n0 = word(o + 2 * PJD_WORD_STRIDE);
+        n1 = word(o + 3 * PJD_WORD_STRIDE);
+        off = o + 2 * PJD_WORD_STRIDE;
+        r = 32 * (kk + 1) - (int)p;                        // 0..31
+    }
+    // the next 32 bits: right after a service (r >= 0) / anywhere between two services
+    __device__ __forceinline__ uint32_t peek0() const { return __builtin_amdgcn_alignbit(w0, w1, (uint32_t)r); }
+    __device__ __forceinline__ uint32_t peek1() const
+    {
+        const bool in1 = r < 0;
+        return __builtin_amdgcn_alignbit(in1 ? w1 : w0, in1 ? w2 : w1, (uint32_t)r & 31u);
+    }
+    __device__ __forceinline__ void drop(uint32_t n) { r -= (int)n; }
+    __device__ __forceinline__ void service()
+    {
+        // words used up: 0, 1 or 2 -- as two shifts by one word (a three-way choice per register is what the compiler turns into an
+        // array in scratch memory indexed by the count)
+        const bool j1 = r < 0, j2 = r < -32;
+        uint32_t t0 = j1 ? w1 : w0, t1 = j1 ? w2 : w1, t2 = j1 ? n0 : w2, t3 = j1 ? n1 : n0;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+        w0 = j2 ? t1 : t0; w1 = j2 ? t2 : t1; w2 = j2 ? t3 : t2;
+        off += (j1 ? PJD_WORD_STRIDE : 0u) + (j2 ? PJD_WORD_STRIDE : 0u);
+        r &= 31;
+        // the copies above stay ahead of the loads: the loads then target n0 / n1 directly and are first waited for at the next service
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
+        n0 = word(off);
+        n1 = word(off + PJD_WORD_STRIDE);
+    }
+};
+
 // LDS is addressed by ABSOLUTE byte address (the tables' offsets carry the base of the kernel's dynamic LDS): indexing a pointer
 // derived from the extern array makes the compiler add that base -- a link-time constant it cannot fold -- on every access.
 __device__ __forceinline__ uint32_t lds_abs(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
@@ -354,7 +410,7 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
     jout = 1;
     oldA_st = 0xffffffffu; oldA_rem = 0;
     if (p >= end_bit) return SPAN_END;
-    BitWin w;
+    BitWin2 w;
     w.init(wave_words, col, p);
     uint32_t ra, x;
     {
@@ -365,14 +421,13 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
     uint32_t next_chk = K.chk_bits;
     uint32_t lim = next_chk < end_bit ? next_chk : end_bit;     // one compare per symbol covers "subsequence end" and "next checkpoint"
     int res = SPAN_END;
-    // on entry p < lim: p <= 26 bits (a symbol that started before the lane's first byte) and p < end_bit
-    for (;;) {
-        const uint32_t pk = w.peek();
+    // one step from the window `pk`; true: the pass ends here
+    auto step = [&](uint32_t pk) -> bool {
         const uint2 nx = lds_u32x2(ra);                                     // what follows this unit: issued beside the table lookup
         const uint32_t tab = (zb == 63) ? (x & 0xffffu) : (x >> 16);
         const uint32_t e = lut_lookup_pair(P.lbase, tab, pk);
-        // two symbols in this step where the table holds the pair (AC tables only), the first one leaves the unit open and the
-        // second one still starts before the next checkpoint / the subsequence's end -- else the first alone
+        // two symbols in this step where the table holds the pair, the first one leaves the unit open and the second one still
+        // starts before the next checkpoint / the subsequence's end -- else the first alone
         const uint32_t u1 = PJD_LUT_USED(e), u12 = PJD_LUT_PAIR_USED(e);
         const int z1 = zb - (int)PJD_LUT_ADV(e);
         const bool pair = u12 != 0 && z1 >= 0 && p + u1 < lim;
@@ -388,14 +443,14 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
         x = done ? nx.x : x;
         ndu = add_flag(ndu, done);
         if (p >= lim) {
-            if (p >= end_bit) break;
+            if (p >= end_bit) return true;
             const uint32_t st = (p << 14) | ((ra - P.xbase) << 6) | (uint32_t)zb;      // p < 2^14, record offset < 256, zb < 64
             if (BRIDGE) {
                 const uint32_t a = K.state[j * 64];
-                if (a == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; break; }
+                if (a == st) { ndu += K.rem[j * 64]; res = SPAN_MERGED; return true; }
                 if (j == 1) {
                     oldA_st = a; oldA_rem = K.rem[64];
-                    if (st == Bst) { res = SPAN_MERGED_B; break; }
+                    if (st == Bst) { res = SPAN_MERGED_B; return true; }
                 }
             }
             K.state[j * 64] = st;
@@ -404,6 +459,13 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
             next_chk += K.chk_bits;
             lim = next_chk < end_bit ? next_chk : end_bit;
         }
+        return false;
+    };
+    // on entry p < lim: p <= 26 bits (a symbol that started before the lane's first byte) and p < end_bit
+    for (;;) {
+        if (step(w.peek0())) break;
+        if (step(w.peek1())) break;
+        w.service();
     }
     c = P.dus1 - ((ra - P.xbase) >> 4);
     z = 63u - (uint32_t)zb;
@@ -629,7 +691,8 @@ __device__ __forceinline__ int jpeg_value(uint32_t pk, uint32_t used, uint32_t s
 
 // One STEP of the write pass: one symbol, or the PAIR the table entry holds (AC symbols, the first leaves the unit open and the
 // second still starts before `end_bit`).  Returns the step word (entry A | entry B << 16, pjd_internal.h); updates the state.
-__device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState &S, uint32_t &D, OutCtx &O, uint32_t end_bit)
+template <bool FIRST>
+__device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin2 &w, WState &S, uint32_t &D, OutCtx &O, uint32_t end_bit)
 {
     const bool is_dc = (S.zb == 63);
     if (__builtin_expect(is_dc && D == O.mark_D, 0)) {                      // this unit opens an IDCT workgroup's range
@@ -639,7 +702,7 @@ __device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin &w, WState
         O.marks[O.mark_next++] = m;
         O.mark_D += O.ru;
     }
-    const uint32_t pk = w.peek();
+    const uint32_t pk = FIRST ? w.peek0() : w.peek1();                      // FIRST: the step right after a service of the window
     const uint4 nx = lds_u32x4(S.ra);                                       // the unit after this one
     const uint32_t tab = is_dc ? (S.x & 0xffffu) : (S.x >> 16);
     const uint32_t e = lut_lookup_pair(lbase, tab, pk);
@@ -683,7 +746,7 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
                                            uint32_t &p, uint32_t &c, uint32_t &z, uint32_t end_bit,
                                            uint32_t &err, uint32_t &D, uint32_t D_end, OutCtx &O)
 {
-    BitWin w;
+    BitWin2 w;
     w.init(wave_words, col, p);
     WState S;
     S.p = p; S.zb = 63 - (int)z; S.emax = 0; S.umin = 0xffffffffu;
@@ -696,12 +759,14 @@ __device__ __forceinline__ void write_span(const PhaseCtx &P, pjd_gptr wave_word
     bool running = S.p < end_bit && D < D_end;
     while (running) {                                                        // one group per iteration
 #pragma unroll
-        for (int k = 1; k < PJD_STAGE_ENTRIES / 2; k++)
+        for (int k = 1; k < PJD_STAGE_ENTRIES / 2; k++) {
             if (running) {
-                O.stage[k * 64] = write_step(P.lbase, w, S, D, O, end_bit);
+                O.stage[k * 64] = (k & 1) ? write_step<true>(P.lbase, w, S, D, O, end_bit) : write_step<false>(P.lbase, w, S, D, O, end_bit);
                 O.n += 2;
                 running = S.p < end_bit && D < D_end;
             }
+            if (!(k & 1) || k == PJD_STAGE_ENTRIES / 2 - 1) w.service();     // the window: after every second step, and before the next group
+        }
         if ((O.n & (PJD_STAGE_ENTRIES - 1)) == 0) {                          // the group is full
             stage_flush(O, O.n - PJD_STAGE_ENTRIES);
             if (running) {
