@@ -194,7 +194,7 @@ void pjd_close(pjd_ctx *ctx);
 /* How batches created on this context from now on are planned.  The entropy decoder cuts every bitstream into lanes; short lanes
  * finish ONE batch sooner (every pass of every chain is shorter), long lanes cost less work per byte (fewer re-synchronisation
  * passes), which is what counts when several batches are decoded at once (pjd_pipeline, a serving loop).  Measured on the default
- * workload of bench.py: latency plan 2.24 ms for a batch alone / 116 GPix/s with four in flight, throughput plan 2.66 ms / 122.
+ * workload of bench.py: latency plan 2.15 ms for a batch alone / 121 GPix/s with four in flight, throughput plan 2.50 ms / 130.
  * Pictures are identical either way.  Default: PJD_PLAN_LATENCY (PJD_PLAN_MODE=throughput in the environment changes it).      */
 #define PJD_PLAN_LATENCY     0
 #define PJD_PLAN_THROUGHPUT  1
