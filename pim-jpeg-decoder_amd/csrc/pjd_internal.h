@@ -7,7 +7,9 @@
 #include <stdint.h>
 
 // ---- tunables -----------------------------------------------------------------
+#ifndef PJD_SUB_BYTES_MIN
 #define PJD_SUB_BYTES_MIN  128      // Huffman subsequence (bytes of bitstream per decode lane): chosen per batch
+#endif
 #define PJD_SUB_BYTES_MAX  1024     //   by the planner (multiple of 64 in this range), see pjd_plan.cpp
 #define PJD_HUFF_LANES     64       // subsequences per wave: lanes exchange states by shuffles, no barriers
 #ifndef PJD_HUFF_WAVES
