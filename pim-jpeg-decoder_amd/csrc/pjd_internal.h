@@ -236,7 +236,7 @@ struct PjdDevScan {
 // (code and value bits), it is a valid run/size symbol (not an EOB) or a valid DC symbol, and the rest of the 9 bits determine the next
 // code (any valid AC symbol, an EOB too; its value bits may lie outside) -- for a DC table: a code of the AC table its components
 // decode with (PjdDevTset::pair_ac):
-//   bits 20..16 bits consumed by both symbols (2..27+; 0: no pair here)        bits 27..21 slots both use up (advance 1 + advance 2)
+//   bits 20..16 bits consumed by both symbols (2..27+; the symbol's own: no pair here)        bits 27..21 slots both use up (advance 1 + advance 2)
 //   bits 31..28 value bits (size) of the second symbol (its value is the last `size` of the bits both consume)
 // Every pass takes a pair in ONE step when the first symbol neither completes the unit nor reaches the next checkpoint /
 // subsequence end: dense streams average 5 bits per symbol, 60 % of the steps there are pairs (profiles/r03_experiments.md).
@@ -256,7 +256,7 @@ struct PjdDevTset {
 #define PJD_LUT_USED(e)  ((e) & 31u)
 #define PJD_LUT_ADV(e)   (((e) >> 5) & 127u)      // run + 1; 96 for an EOB
 #define PJD_LUT_SIZE(e)  (((e) >> 12) & 15u)
-#define PJD_LUT_PAIR_USED(e)  (((e) >> 16) & 31u)  // of an L1 entry: 0 = no pair
+#define PJD_LUT_PAIR_USED(e)  (((e) >> 16) & 31u)  // == PJD_LUT_USED(e): no pair (the pair field then repeats the symbol's used / advance)
 #define PJD_LUT_PAIR_ADV(e)   (((e) >> 21) & 127u)
 #define PJD_LUT_PAIR_SIZE2(e) ((e) >> 28)
 #define PJD_LUT_EOB      0x0800u

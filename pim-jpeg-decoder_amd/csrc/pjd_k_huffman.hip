@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256) void pjd_k_build_tables(PjdDevBatch B)
             if (m2 && PJD_LUT_SIZE(m2) < PJD_LUT_BADSYM && PJD_LUT_USED(m) + PJD_LUT_USED(m2) <= 31u)
                 pair = (PJD_LUT_USED(m) + PJD_LUT_USED(m2)) | ((PJD_LUT_ADV(m) + PJD_LUT_ADV(m2)) << 5) | (PJD_LUT_SIZE(m2) << 12);   // size 2: bits 31..28 of the entry
         }
+        // no pair: the pair field repeats the symbol's own used / advance (a "pair" that is the symbol alone), so the state-only
+        // passes need not ask whether there is one; the write pass tells a real pair by used12 != used
+        if (!pair) pair = e & 0xfffu;
         L1[idx] = (e & 0xffffu) | (pair << 16);
     }
     for (uint32_t j = tid; j < ((p1 - p0) << PJD_L2_BITS); j += 256) {
@@ -375,8 +378,10 @@ __device__ __forceinline__ uint32_t lut_lookup_pair(uint32_t lbase, uint32_t tab
 {
     uint32_t e = lds_u32(tab + 4 * __builtin_amdgcn_ubfe(pk, 32 - PJD_LUT_BITS, PJD_LUT_BITS));
     // code longer than 9 bits (a pointer entry consumes no bits): one more read, in the 128-entry table of this 9-bit prefix
-    if (__builtin_expect(PJD_LUT_USED(e) == 0, 0))
+    if (__builtin_expect(PJD_LUT_USED(e) == 0, 0)) {
         e = lds_u16(lbase + 2 * ((((e >> 5) & 0x7ffu) << PJD_L2_BITS) + ((pk >> 16) & ((1u << PJD_L2_BITS) - 1u))));
+        e |= e << 16;                                  // no pair: as the first-level entries say it (the size lands in size2: unused)
+    }
     return e;
 }
 // the symbol alone (the low half)
@@ -430,7 +435,7 @@ __device__ __forceinline__ int sync_span(const PhaseCtx &P, pjd_gptr wave_words,
         // starts before the next checkpoint / the subsequence's end -- else the first alone
         const uint32_t u1 = PJD_LUT_USED(e), u12 = PJD_LUT_PAIR_USED(e);
         const int z1 = zb - (int)PJD_LUT_ADV(e);
-        const bool pair = u12 != 0 && z1 >= 0 && p + u1 < lim;
+        const bool pair = z1 >= 0 && p + u1 < lim;                          // (an entry without a pair repeats the symbol in its pair field)
         const uint32_t used = pair ? u12 : u1;
         w.drop(used);
         p += used;
@@ -708,7 +713,7 @@ __device__ __forceinline__ uint32_t write_step(uint32_t lbase, BitWin2 &w, WStat
     const uint32_t e = lut_lookup_pair(lbase, tab, pk);
     const uint32_t u1 = PJD_LUT_USED(e), size1 = PJD_LUT_SIZE(e), adv1 = PJD_LUT_ADV(e);
     const uint32_t u12 = PJD_LUT_PAIR_USED(e), adv12 = PJD_LUT_PAIR_ADV(e), size2 = PJD_LUT_PAIR_SIZE2(e);
-    const bool pair = u12 != 0 && S.zb >= (int)adv1 && S.p + u1 < end_bit;
+    const bool pair = u12 != u1 && S.zb >= (int)adv1 && S.p + u1 < end_bit;
     O.npair += pair ? 1u : 0u;
     // values: `size` bits after the code(s); an invalid entry (size field 14 / 15) yields garbage here and sends the lane to the
     // careful pass through S.emax
