@@ -293,6 +293,11 @@ int  pjd_exec_dpu_payload(pjd_ctx *ctx, const uint32_t *metadata, int16_t *mcus,
 /* Host-only planning: what a batch of these images would occupy (no device needed).
  * Fills everything in `info` except device_bytes / n_fallback.                   */
 int  pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pjd_batch_info *info);
+/* Debug, host-only: the bound behind the size of a picture's lane streams -- the fewest bits of bitstream per step of the entropy
+ * decoder's write pass (one symbol, or the pair one table lookup yields) that ANY stream coded with this picture's Huffman tables can
+ * sustain, x 256 (the minimum mean weight of a cycle of the step graph, pim-jpeg-decoder_amd/csrc/pjd_plan.cpp).  PJD_E_ARG for a
+ * picture that does not take the parallel decoder.  tests/test_planner_bound.py recomputes it another way.                        */
+int  pjd_plan_step_bits(const pjd_image_desc *image, uint32_t *step_bits_x256);
 
 /* Page-locked host memory (hipHostMalloc) for pjd_batch_download_packed; NULL on failure.       */
 void *pjd_host_alloc(uint64_t bytes);

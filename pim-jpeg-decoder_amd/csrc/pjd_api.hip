@@ -889,6 +889,18 @@ int pjd_plan_info(const pjd_image_desc *images, int n_images, int out_format, pj
     return PJD_OK;
 }
 
+int pjd_plan_step_bits(const pjd_image_desc *image, uint32_t *step_bits_x256)
+{
+    if (!image || !step_bits_x256) return PJD_E_ARG;
+    PjdPlan P;
+    std::string err;
+    int rc = pjd_make_plan(image, 1, PJD_OUT_RGB8, P, err);
+    if (rc != PJD_OK) return rc;
+    if (P.images.empty() || P.tset_step_bits.empty() || (P.images[0].flags & PJD_IF_SEQUENTIAL)) return PJD_E_ARG;   // no lane streams for this picture
+    *step_bits_x256 = P.tset_step_bits[P.images[0].tset];
+    return PJD_OK;
+}
+
 uint64_t pjd_batch_output_size(pjd_batch *b, int image)
 {
     if (!b || image < 0 || (size_t)image >= b->plan.host.size()) return 0;

@@ -73,8 +73,9 @@
 #define PJD_WORD_ROWS(sub_bytes)  ((sub_bytes) / 4 + 8)
 // Slots (2 bytes each) of a lane's region.  The write pass emits one 32-bit STEP word per decode step -- one symbol, or the PAIR of
 // symbols one table lookup yields (below).  How many steps a lane of `sub_bytes` bytes can take follows from the PICTURE's table set:
-// the planner computes the fewest bits per step any stream can sustain with it (Annex-K tables: 4 -- a flat unit, DC + EOB, is one
-// step of 4 bits; tables fitted to a dense picture: 4-6; without the DC pairs it was 2).
+// the planner computes the fewest bits per step any stream can sustain with it (Annex-K tables: 3.5 -- a chroma unit of DC 0, one
+// +-1 coefficient and an EOB is the pair DC + coefficient, then the EOB: 7 bits in two steps; tables fitted to a dense picture: 4-5;
+// without the DC pairs it was 2).
 // A region is a sequence of 32-byte GROUPS: one head word + PJD_GROUP_STEPS (7) step words (below), a whole number of groups.
 // The write pass still checks the bound (PJD_FLAG_OVERFLOW) before every flush.
 #define PJD_GROUP          16       // slots per group = what the write pass stages between two flushes (8 dwords)

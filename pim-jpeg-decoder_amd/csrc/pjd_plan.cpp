@@ -196,7 +196,7 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
     std::map<std::string, uint32_t> tset_of;       // raw bytes of a deduplicated table list -> table set
     std::vector<char> tset_parallel;               // per set: the two-level tables fit the parallel decoder
     std::vector<uint32_t> tset_min_bits;           // per set: fewest bits (code + value bits) any of its symbols consumes
-    std::vector<uint32_t> tset_step_bits;          // per set: fewest bits per step of the write pass, x 256 (min_step_bits_x256)
+    std::vector<uint32_t> &tset_step_bits = P.tset_step_bits;      // per set: fewest bits per step of the write pass, x 256 (min_step_bits_x256)
     uint64_t ent_off = 0;                          // slots of the lane regions handed out so far
     for (int i = 0; i < n; i++) {
         const pjd_image_desc &d = images[i];
@@ -276,28 +276,24 @@ int pjd_make_plan(const pjd_image_desc *images, int n, int out_format, PjdPlan &
 
         // ---- Huffman tables: dedupe the (up to) 3 DC + 3 AC tables the components reference, then find or make
         //      the table SET (identical lists share decode tables, and their waves can share a workgroup)
+        //      A DC table's decode table holds the pairs "DC symbol + the unit's first AC symbol", so it belongs to ONE AC table: two
+        //      components with the same DC table and different AC tables get a DC slot each (at most 3 + 3 slots).
         int nt = 0;
         const pjd_huff_table *seen[PJD_MAX_TABLES];
         uint8_t seen_ac[PJD_MAX_TABLES];
-        for (int c = 0; c < (int)g.ncomp && !progressive; c++)
-            for (int a = 0; a < 2; a++) {
-                const pjd_huff_table *t = a ? &d.ac[d.comp_ac[c]] : &d.dc[d.comp_dc[c]];
-                int sl = -1;
-                for (int k = 0; k < nt; k++)
-                    if (seen_ac[k] == a && same_table(*seen[k], *t)) { sl = k; break; }
-                if (sl < 0) { sl = nt++; seen[sl] = t; seen_ac[sl] = (uint8_t)a; }
-                g.tbl_slot[c][a] = (uint8_t)sl;
-            }
-        // of a DC table: the AC table every component that uses it decodes with (the tables then hold the pair "DC symbol + first AC symbol")
-        uint8_t pair_ac[PJD_MAX_TABLES];
+        uint8_t pair_ac[PJD_MAX_TABLES];               // of a DC slot: its AC slot
         std::memset(pair_ac, 0xff, sizeof pair_ac);
-        {
-            bool clash[PJD_MAX_TABLES] = {false};
-            for (int c = 0; c < (int)g.ncomp && !progressive; c++) {
-                const uint8_t dslot = g.tbl_slot[c][0], aslot = g.tbl_slot[c][1];
-                if (pair_ac[dslot] == 0xff && !clash[dslot]) pair_ac[dslot] = aslot;
-                else if (pair_ac[dslot] != aslot) { clash[dslot] = true; pair_ac[dslot] = 0xff; }
-            }
+        for (int c = 0; c < (int)g.ncomp && !progressive; c++) {
+            const pjd_huff_table *ta = &d.ac[d.comp_ac[c]], *td = &d.dc[d.comp_dc[c]];
+            int sa = -1, sd = -1;
+            for (int k = 0; k < nt; k++)
+                if (seen_ac[k] == 1 && same_table(*seen[k], *ta)) { sa = k; break; }
+            if (sa < 0) { sa = nt++; seen[sa] = ta; seen_ac[sa] = 1; }
+            for (int k = 0; k < nt; k++)
+                if (seen_ac[k] == 0 && pair_ac[k] == (uint8_t)sa && same_table(*seen[k], *td)) { sd = k; break; }
+            if (sd < 0) { sd = nt++; seen[sd] = td; seen_ac[sd] = 0; pair_ac[sd] = (uint8_t)sa; }
+            g.tbl_slot[c][0] = (uint8_t)sd;
+            g.tbl_slot[c][1] = (uint8_t)sa;
         }
         std::string key;
         key.reserve((size_t)nt * 180 + 8);

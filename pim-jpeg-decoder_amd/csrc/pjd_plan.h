@@ -52,6 +52,7 @@ struct PjdPlan {
     uint32_t max_lut_bytes = 0;            // largest blob (dynamic LDS of the Huffman kernel)
     uint64_t pixels = 0, ecs_bytes = 0, out_bytes = 0;
     int plan_mode = 0;                     // PJD_PLAN_*
+    std::vector<uint32_t> tset_step_bits;  // per table set: fewest bits of stream per step of the write pass, x 256 (sizes the lane regions)
 };
 
 // Returns PJD_OK or PJD_E_ARG (with a message in `err`).

@@ -525,6 +525,18 @@ def split_plan(desc, world, rank):
             "ecs_delta": (int(shard.ecs or 0) - int(desc.ecs or 0))}
 
 
+def plan_step_bits(desc):
+    """Host-only, debug: fewest bits of stream per write-pass step the picture's tables can be made to sustain (a float; pjd.h)."""
+    L = dev_lib()
+    L.pjd_plan_step_bits.restype = C.c_int32
+    L.pjd_plan_step_bits.argtypes = [C.POINTER(ImageDesc), C.POINTER(C.c_uint32)]
+    v = C.c_uint32()
+    rc = L.pjd_plan_step_bits(C.byref(desc), C.byref(v))
+    if rc != 0:
+        raise PjdError(f"pjd_plan_step_bits failed ({rc})")
+    return v.value / 256.0
+
+
 def plan_info(descs, out_format=OUT_RGB8):
     """Host-only: what a batch of these images would occupy (no GPU needed)."""
     L = dev_lib()
