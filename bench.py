@@ -499,7 +499,7 @@ def main():
                        "bytes_per_pixel": main_rates["bytes_per_pixel"], "table_sets": info["n_table_sets"],
                        "huffman_lanes": info["n_subsequences"], "sub_bytes": info["sub_bytes"],
                        "device_bytes_per_batch": int(info["device_bytes"]), "lane_stream_capacity_bytes": int(info["coef_bytes"]),
-                       "lane_stream_bytes_used": int(info["n_steps"] * 4 * 8 // 7),
+                       "lane_stream_bytes_used": int(info["n_steps"] * 4 * 8 // 7), "fullest_lane_region": round(info["lane_fill_x1024"] / 1024.0, 3),
                        "exact_kernel_images": main_rates["exact_kernel_images"],
                        "hip_graph": not args.no_graph, "batches_in_flight": nfl, "host_nproc": os.cpu_count(),
                        "plan_mode": "throughput" if info["plan_mode"] else "latency",

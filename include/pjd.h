@@ -185,6 +185,9 @@ typedef struct pjd_batch_info {
                                           whole wave decodes one lane's subsequence several times faster), and the lanes walked */
     uint64_t n_steps;                  /* last decode: steps of the write pass (a step emits one entry, or the two entries of a symbol
                                           pair that one table lookup yields): n_entries / n_steps = symbols per step               */
+    uint32_t lane_fill_x1024;          /* last decode: the fullest lane region, slots written x 1024 / its capacity (capacities are a
+                                          bound computed from the picture's Huffman tables: never above 1024)                    */
+    uint32_t reserved2_;
 } pjd_batch_info;
 
 /* ---- context --------------------------------------------------------------- */

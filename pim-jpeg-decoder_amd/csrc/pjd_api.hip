@@ -815,6 +815,7 @@ int pjd_batch_get_info(pjd_batch *b, pjd_batch_info *info)
         for (int r = 0; r < PJD_FLAG_REASONS && r < 8; r++) info->flag_waves[r] = st[PJD_STAT_FLAG0 + r];
         info->n_entries = st[PJD_STAT_ENTRIES];               // entries the lanes emitted in the last decode
         info->n_steps = st[PJD_STAT_STEPS];                   // ... in this many steps of the write pass
+        info->lane_fill_x1024 = (uint32_t)st[PJD_STAT_FILL];  // the fullest lane region
     }
     info->n_huff_workgroups = P.hwgs.size();
     if (b->dev.dbg && b->decoded) {          // PJD_DEBUG_STATS: wave timeline of the last decode (units of 10 ns)

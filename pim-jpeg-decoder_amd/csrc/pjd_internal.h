@@ -160,6 +160,7 @@ enum {
 #define PJD_STAT_FLAG0 4
 #define PJD_STAT_ENTRIES 11  // PjdDevBatch::stats[]: entries (= Huffman symbols) the lanes emitted in this decode
 #define PJD_STAT_STEPS   14  // step words they took for it (a step holds one symbol or a pair)
+#define PJD_STAT_FILL    15  // fullest lane region of the decode: slots written x 1024 / PJD_LANE_CAP of its picture (atomic max)
 #define PJD_STAT_WALKS   12  // cooperative walks (a wave taking over its few remaining active lanes), 13: lanes walked in them
 
 struct PjdDevImage {

@@ -1455,12 +1455,14 @@ __global__ __launch_bounds__(PJD_HUFF_THREADS) PJD_HUFF_OCC_ATTR void pjd_k_huff
     // to the exact kernel is decided per picture once all its waves have reported (pjd_k_image_verdict): what lies behind the
     // picture's first entropy-coding error is never decoded by the reference and does not count.
     uint32_t wflag = flag, went = npair, wsteps = g.valid ? li.n_ent / 2 - (li.n_ent + PJD_GROUP - 1) / PJD_GROUP : 0, wpos = (flag && g.valid) ? g.base_bit : 0xffffffffu;
+    uint32_t wfill = g.valid ? (uint32_t)(((uint64_t)li.n_ent << 10) / im.lane_cap) : 0u;      // how full the lane's region got (the planner's bound at work)
     for (int off = 1; off < 64; off <<= 1) {
         wflag |= __shfl_xor(wflag, off); went += __shfl_xor(went, off); wsteps += __shfl_xor(wsteps, off);
+        { const uint32_t o = __shfl_xor(wfill, off); wfill = o > wfill ? o : wfill; }
         const uint32_t o = __shfl_xor(wpos, off);
         wpos = o < wpos ? o : wpos;
     }
-    if (l == 0) { atomicAdd(B.stats + PJD_STAT_ENTRIES, (unsigned long long)(went + wsteps)); atomicAdd(B.stats + PJD_STAT_STEPS, (unsigned long long)wsteps); }
+    if (l == 0) { atomicAdd(B.stats + PJD_STAT_ENTRIES, (unsigned long long)(went + wsteps)); atomicAdd(B.stats + PJD_STAT_STEPS, (unsigned long long)wsteps); atomicMax(B.stats + PJD_STAT_FILL, (unsigned long long)wfill); }
     if (wflag && l == 0) {
         atomicMin(&B.imstate[hw.image].flag_pos, wpos);
         for (int r = 0; r < PJD_FLAG_REASONS; r++)

@@ -68,7 +68,8 @@ class BatchInfo(C.Structure):
                 ("fix_rounds", C.c_uint64), ("fix_lane_passes", C.c_uint64),
                 ("sub_bytes", C.c_uint32), ("n_table_sets", C.c_uint32), ("n_huff_waves", C.c_uint64),
                 ("n_entries", C.c_uint64), ("exact_fallback_ms", C.c_float), ("n_entropy_errors", C.c_uint32),
-                ("flag_waves", C.c_uint64 * 8), ("huff_lds_bytes", C.c_uint32), ("plan_mode", C.c_uint32), ("walks", C.c_uint64), ("walk_lanes", C.c_uint64), ("n_steps", C.c_uint64)]
+                ("flag_waves", C.c_uint64 * 8), ("huff_lds_bytes", C.c_uint32), ("plan_mode", C.c_uint32), ("walks", C.c_uint64), ("walk_lanes", C.c_uint64), ("n_steps", C.c_uint64),
+                ("lane_fill_x1024", C.c_uint32), ("reserved2_", C.c_uint32)]
 
 
 SPLIT_MAX_DEVICES = 16

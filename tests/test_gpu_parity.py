@@ -644,6 +644,34 @@ def test_sparsest_streams_stay_on_the_parallel_path(ctx, port):
             assert s == want["huff_rc"] and np.array_equal(o, want["rgb"]), i
 
 
+def test_lane_regions_hold_every_stream_and_are_not_oversized(ctx):
+    """Lane regions are sized from a bound computed from the picture's Huffman tables (fewest bits per write-pass step, pjd_plan.cpp;
+    tests/test_planner_bound.py recomputes it).  pjd_batch_info.lane_fill_x1024 reports the fullest region of a decode: never above its
+    capacity on any kind of picture -- flat ones, whose streams run at the bound's own rate, included -- and the flat pictures come
+    within a factor 1.7 of it (a bound that loose would still be safe, but would mean the regions are sized for nothing real)."""
+    import pjd_amd
+    synth = _synth()
+    sets = {
+        "flat fitted": [synth.make(444, 460, 91, 5, synth.SUB_422, 0, 1.0, True), synth.make(649, 513, 92, 5, synth.SUB_444, 0, 1.0, True),
+                        synth.make(300, 200, 94, 5, synth.SUB_GREY, 0, 1.0, True)],
+        "flat annex-K": [synth.make(444, 460, 91, 5, synth.SUB_420, 0, 1.0, False), synth.make(649, 513, 92, 5, synth.SUB_444, 0, 1.0, False)],
+        "q30": [synth.make(800, 600, 6, 30, synth.SUB_420, 0, 1.0, True), synth.make(800, 600, 6, 30, synth.SUB_420, 0, 1.0, False)],
+        "dense": synth.cfg3_imagenet_like(32, seed=3, detail=synth.DENSE_DETAIL, optimize=True, quality_shift=True),
+        "q100": [synth.make(700, 500, 8, 100, synth.SUB_444, 0, synth.DENSE_DETAIL, True)],
+    }
+    fills = {}
+    for name, jpegs in sets.items():
+        sc = [pjd_amd.Scanned(j) for j in jpegs]
+        with ctx.batch([s.desc for s in sc]) as b:
+            b.upload(); b.decode(); b.sync()
+            info = b.info()
+        assert info["flag_waves"][5] == 0 and info["n_fallback"] == 0, (name, info["flag_waves"])
+        assert 0 < info["lane_fill_x1024"] <= 1024, (name, info["lane_fill_x1024"])
+        fills[name] = info["lane_fill_x1024"] / 1024.0
+    assert fills["flat fitted"] > 0.6 and fills["flat annex-K"] > 0.5, fills
+    assert min(fills.values()) > 0.3, fills
+
+
 def test_two_batches_in_flight_on_two_contexts(port):
     """bench.py's default mode: two contexts (two HIP streams), decodes issued alternately without waiting for the
     other one; both produce the oracle's pictures every time."""
