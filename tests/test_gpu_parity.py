@@ -644,6 +644,88 @@ def test_sparsest_streams_stay_on_the_parallel_path(ctx, port):
             assert s == want["huff_rc"] and np.array_equal(o, want["rgb"]), i
 
 
+def _ideal_steps(desc, ecs):
+    """Steps of a write pass that takes EVERY pair the format allows, from an independent bit-level decode of the stream (pure Python):
+    a step is one symbol, or two when the first (code + value bits) fits 8 bits, leaves its unit open and the second one's CODE fits
+    what is left of 9 bits (pjd_internal.h); lane ends, which break a pair now and then, are not modelled: a lower bound."""
+    def codes(t):                                        # canonical Huffman: {(length, code): symbol}
+        out, code = {}, 0
+        for ln in range(1, 17):
+            for q in range(t.offsets[ln - 1], t.offsets[ln]):
+                out[(ln, code)] = t.symbols[q]
+                code += 1
+            code <<= 1
+        return out
+    bits = np.unpackbits(np.frombuffer(bytes(ecs) + b"\0" * 8, np.uint8))
+    comps = [0] * (desc.h_samp * desc.v_samp) + list(range(1, desc.num_components))
+    dc = {c: codes(desc.dc[desc.comp_dc[c]]) for c in range(desc.num_components)}
+    ac = {c: codes(desc.ac[desc.comp_ac[c]]) for c in range(desc.num_components)}
+    mcux = (desc.width + 8 * desc.h_samp - 1) // (8 * desc.h_samp)
+    mcuy = (desc.height + 8 * desc.v_samp - 1) // (8 * desc.v_samp)
+    pos, steps, symbols = 0, 0, 0
+
+    def sym(table):
+        nonlocal pos
+        code = 0
+        for ln in range(1, 17):
+            code = (code << 1) | int(bits[pos + ln - 1])
+            if (ln, code) in table:
+                pos += ln
+                return ln, table[(ln, code)]
+        raise AssertionError("no code")
+
+    for _ in range(mcux * mcuy):
+        for c in comps:
+            # the unit's symbols: (code length, total bits, ends the unit)
+            seq = []
+            ln, s_ = sym(dc[c]); pos += s_; seq.append((ln, ln + s_, False))
+            slot = 1
+            while slot < 64:
+                ln, s_ = sym(ac[c])
+                if s_ == 0:
+                    seq.append((ln, ln, True)); break
+                run, size = s_ >> 4, s_ & 15
+                pos += size
+                slot += run + 1
+                seq.append((ln, ln + size, slot > 63))
+            symbols += len(seq)
+            k = 0
+            while k < len(seq):
+                first = seq[k]
+                if k + 1 < len(seq) and first[1] <= 8 and not first[2] and first[1] + seq[k + 1][0] <= 9:
+                    k += 2
+                else:
+                    k += 1
+                steps += 1
+    return steps, symbols
+
+
+def test_write_pass_takes_every_pair_the_tables_allow(ctx):
+    """The decode tables are built on the GPU (pjd_k_build_tables) and pictures come out right whether or not a pair is in them: a
+    missing pair costs time, never correctness, so nothing else would notice (round 4: components that shared a DC table but not an
+    AC table had silently lost the DC pairs).  Here the steps the write pass took (pjd_batch_info.n_steps) are compared with a
+    pure-Python bit-level decode of the same stream that pairs whatever the format allows: at most one broken pair per lane apart."""
+    import pjd_amd
+    synth = _synth()
+    cases = {
+        "annex-K 4:2:0": synth.make(200, 152, 21, 85, synth.SUB_420, 0),
+        "fitted dense 4:4:4": synth.make(160, 120, 22, 95, synth.SUB_444, 0, synth.DENSE_DETAIL, True),
+        "fitted flat 4:4:4": synth.make(320, 240, 23, 5, synth.SUB_444, 0, 1.0, True),
+        "fitted 4:2:2 q50": synth.make(201, 77, 24, 50, synth.SUB_422, 0, 1.0, True),
+        "grey": synth.make(199, 99, 25, 75, synth.SUB_GREY, 0),
+    }
+    for name, jpeg in cases.items():
+        s = pjd_amd.Scanned(jpeg)
+        assert s.valid
+        want_steps, want_symbols = _ideal_steps(s.desc, s.ecs())
+        with ctx.batch([s.desc]) as b:
+            b.upload(); b.decode(); b.sync()
+            info = b.info()
+        assert info["n_fallback"] == 0 and info["n_sequential"] == 0, name
+        assert info["n_entries"] == want_symbols, (name, info["n_entries"], want_symbols)
+        assert want_steps <= info["n_steps"] <= want_steps + info["n_subsequences"], (name, info["n_steps"], want_steps, info["n_subsequences"])
+
+
 def test_lane_regions_hold_every_stream_and_are_not_oversized(ctx):
     """Lane regions are sized from a bound computed from the picture's Huffman tables (fewest bits per write-pass step, pjd_plan.cpp;
     tests/test_planner_bound.py recomputes it).  pjd_batch_info.lane_fill_x1024 reports the fullest region of a decode: never above its
