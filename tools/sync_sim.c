@@ -664,3 +664,62 @@ void sim_waves(const Sim *s, int S, int nchk, int walk_max, int nhyp, double *ou
         out[0] += t; if (t > out[1]) out[1] = t; out[2]++;
     }
 }
+
+// ---- round 4, #31: can a speculative pass guess the MCU phase from what it decodes? ------------------------------------------
+// Natural pictures: luma units are long, chroma units short.  The detector keeps the bit lengths of the last `dus` units it completed,
+// each with the phase position it decoded it at, and -- every `every` units -- re-labels its phase to the cyclic shift under which the
+// long units sit on luma positions (score = sum of lengths on luma positions minus `wc` x sum on chroma positions), if that shift beats
+// the current labelling by `margin` bits.  sim_exit_right: lanes of S bytes started at (lane start, DC expected, phase 0): out[0] = lanes,
+// out[1] = lanes whose exit state is the true one without the detector, out[2] = with it; out[3] / out[4] = sum of bits until in step
+// (lanes that get there), out[5] / out[6] = lanes that get there.
+typedef struct { long len[8]; int pos[8]; int n; long last_p; int since; } Det;
+static void det_unit(const Sim *s, Det *d, long p_now, int pos_decoded, int *c, int every, int wc, long margin)
+{
+    const int dus = s->dus;
+    for (int k = dus - 1; k > 0; k--) { d->len[k] = d->len[k - 1]; d->pos[k] = d->pos[k - 1]; }
+    d->len[0] = p_now - d->last_p; d->pos[0] = pos_decoded; d->last_p = p_now;
+    if (d->n < dus) d->n++;
+    d->since++;
+    if (d->n < dus || d->since < every) return;
+    long best = 0, cur = 0; int bs = 0;
+    for (int sh = 0; sh < dus; sh++) {
+        long sc = 0;
+        for (int k = 0; k < dus; k++) { const int q = (d->pos[k] + sh) % dus; sc += q < s->nluma ? d->len[k] : -(long)wc * d->len[k]; }
+        if (sh == 0) cur = sc;
+        if (sh == 0 || sc > best) { best = sc; bs = sh; }
+    }
+    if (bs != 0 && best > cur + margin) {
+        *c = (*c + bs) % dus;
+        for (int k = 0; k < dus; k++) d->pos[k] = (d->pos[k] + bs) % dus;
+        d->since = 0;
+    }
+}
+static St run_lane_det(const Sim *s, St in, long end_bit, int use, int every, int wc, long margin, long *sync_at)
+{
+    Det d; memset(&d, 0, sizeof d); d.last_p = in.p;
+    long ndu = 0; *sync_at = -1;
+    while (in.p < end_bit && in.p < s->nbits) {
+        if (*sync_at < 0 && s->tz[in.p] == in.z + 1 && s->tc[in.p] == in.c) *sync_at = in.p;
+        const long before = ndu; const int pos = in.c;
+        if (step(s, &in.p, &in.z, &in.c, &ndu, 1)) break;
+        if (use && ndu != before) det_unit(s, &d, in.p, pos, &in.c, every, wc, margin);
+    }
+    return in;
+}
+void sim_exit_right(const Sim *s, int S, int every, int wc, long margin, long *out)
+{
+    const long nbytes = s->nbits / 8;
+    const int nl = (int)((nbytes + S - 1) / S);
+    memset(out, 0, 8 * sizeof(long));
+    for (int k = 1; k < nl; k++) {
+        const long p0 = (long)k * S * 8, end = (long)(k + 1) * S * 8;
+        if (end >= s->nbits) break;
+        out[0]++;
+        for (int use = 0; use < 2; use++) {
+            St in = { p0, 0, 0 }; long sync_at;
+            const St ex = run_lane_det(s, in, end, use, every, wc, margin, &sync_at);
+            if (s->tz[ex.p] == ex.z + 1 && s->tc[ex.p] == ex.c) out[1 + use]++;
+            if (sync_at >= 0) { out[3 + use] += sync_at - p0; out[5 + use]++; }
+        }
+    }
+}
