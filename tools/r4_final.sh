@@ -2,6 +2,8 @@
 # round-4: the default bench exactly as the driver runs it (N = 1), twice
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
+# parity first: a subset of the GPU suite on the build that is about to be timed (a sweep without it once reported a faster kernel that decoded garbage)
+timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "reference_hashes or wrap or random_streams" > gpurun_out/parity_first.log 2>&1; rc=$?; echo "parity subset rc=$rc $(tail -1 gpurun_out/parity_first.log)"; [ $rc -ne 0 ] && exit $rc
 for k in 1 2; do
   timeout -k 10 560 python bench.py > gpurun_out/r4_final_$k.log 2> gpurun_out/r4_final_$k.err; echo "bench $k rc=$?"
 done

@@ -2,6 +2,8 @@
 # what a batch alone looks like on an idle device: PJD_IDLE_FORM = chain | groups | pull (the default); parity first
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
+# parity first: a subset of the GPU suite on the build that is about to be timed (a sweep without it once reported a faster kernel that decoded garbage)
+timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "reference_hashes or wrap or random_streams" > gpurun_out/parity_first.log 2>&1; rc=$?; echo "parity subset rc=$rc $(tail -1 gpurun_out/parity_first.log)"; [ $rc -ne 0 ] && exit $rc
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/forms_test.log 2>&1; rc=$?; echo "tests rc=$rc $(tail -1 gpurun_out/forms_test.log)"
 [ $rc -ne 0 ] && { tail -30 gpurun_out/forms_test.log; exit $rc; }
 run() { # label, env...

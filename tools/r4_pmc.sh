@@ -8,6 +8,9 @@ export PJD_SUB_BYTES=$SB
 # the counter passes decode the batch in ONE chain of launches (as with several batches in flight): per-kernel figures are those of
 # whole-batch launches; on an idle device the library issues the same work as two chains (picture groups), traced at the end
 export PJD_GROUPS=1
+mkdir -p "$GRAFT_REPO_ROOT/gpurun_out"
+# parity first: a subset of the GPU suite on the build that is about to be timed (a sweep without it once reported a faster kernel that decoded garbage)
+timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "reference_hashes or wrap or random_streams" > "$GRAFT_REPO_ROOT"/gpurun_out/parity_first.log 2>&1; rc=$?; echo "parity subset rc=$rc $(tail -1 "$GRAFT_REPO_ROOT"/gpurun_out/parity_first.log)"; [ $rc -ne 0 ] && exit $rc
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > "$OUT/counters.txt" 2>&1
 CMD="python3 $GRAFT_REPO_ROOT/bench.py --workload ${WORKLOAD:-cfg3} --no-variants --in-flight 1 --e2e-batches 0 --no-cpu-baseline --no-cli --steps 10"

@@ -2,6 +2,8 @@
 # walker threshold after the B cache (PJD_WALK_MAX overrides the planner's per-picture choice), three repetitions of the default
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
+# parity first: a subset of the GPU suite on the build that is about to be timed (a sweep without it once reported a faster kernel that decoded garbage)
+timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "reference_hashes or wrap or random_streams" > gpurun_out/parity_first.log 2>&1; rc=$?; echo "parity subset rc=$rc $(tail -1 gpurun_out/parity_first.log)"; [ $rc -ne 0 ] && exit $rc
 run() { # label, env...
   label=$1; shift
   env "$@" timeout -k 10 300 python bench.py --e2e-batches 0 --no-cpu-baseline --no-cli --no-variants --steps 150 > gpurun_out/wm.log 2> gpurun_out/wm.err || { echo "$label failed"; tail -3 gpurun_out/wm.err; return; }
